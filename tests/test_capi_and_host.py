@@ -1,0 +1,114 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/xbitops_hip.h declares, argument validation (no compute without a GPU), and the Python
+operator surface mirrors the reference binding's checks (dq_torch_ops.cc:5-9,25-31,49-57)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "xbitops_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(xbit_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_two_launcher_replacements():
+    syms = declared_symbols()
+    assert "xbit_dequant_f16" in syms and "xbit_gemv_f16" in syms
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    from xbitops_amd import _lib
+
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+    assert sorted(_lib.EXPORTS) == declared_symbols()
+    assert native_lib.xbit_abi_version() == 1
+
+
+def test_library_has_no_torch_dependency(native_lib):
+    from xbitops_amd import _lib
+    import subprocess
+
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in out and "c10" not in out
+    assert "amdhip64" in out
+
+
+def test_status_strings(native_lib):
+    from xbitops_amd import _lib
+
+    assert _lib.status_string(0) == "success"
+    for code in (-1, -2, -3, -4, -5):
+        assert _lib.status_string(code).startswith("xbitops:")
+    with pytest.raises(RuntimeError, match="bits must be in 2..8"):
+        _lib.check(-2, "x")
+
+
+def test_capi_rejects_bad_arguments_before_touching_the_gpu(native_lib):
+    lib = native_lib
+    p = 0x1000  # never dereferenced: every call below must fail validation first
+    assert lib.xbit_gemv_f16(None, p, p, p, p, 4, 128, 1, 128, 64, 0, None) == -1
+    assert lib.xbit_gemv_f16(p, p, p, p, p, 1, 128, 1, 128, 64, 0, None) == -2
+    assert lib.xbit_gemv_f16(p, p, p, p, p, 9, 128, 1, 128, 64, 0, None) == -2
+    assert lib.xbit_gemv_f16(p, p, p, p, p, 4, 0, 1, 128, 64, 0, None) == -3
+    assert lib.xbit_gemv_f16(p, p, p, p, p, 4, 128, 0, 128, 64, 0, None) == -4
+    assert lib.xbit_gemv_f16(p, p, p, p, p, 4, 128, 1, 128, 63, 0, None) == -4  # odd n
+    assert lib.xbit_gemv_f16(p, p, p + 2, p, p, 4, 128, 1, 128, 64, 0, None) == -5  # qweight not 4-byte aligned
+    assert lib.xbit_dequant_f16(p, None, p, p, 4, 128, 128, 64, 0, None) == -1
+    assert lib.xbit_dequant_f16(p, p, p, p, 0, 128, 128, 64, 0, None) == -2
+    assert lib.xbit_dequant_f16(p, p, p, p, 4, 128, 0, 64, 0, None) == -4
+    assert lib.xbit_profile_last_ms(None) == -1
+
+
+def _cpu_args(k=128, n=64, bits=4, g=128):
+    qweight = torch.zeros(((k * bits + 31) // 32, n), dtype=torch.int32)
+    scales = torch.ones(((k + g - 1) // g, n), dtype=torch.float16)
+    qzeros = torch.zeros(((k + g - 1) // g, (n * bits + 31) // 32), dtype=torch.int32)
+    return qweight, scales, qzeros
+
+
+def test_ops_reject_cpu_tensors_like_check_cuda(native_lib):
+    import XbitOps
+
+    qweight, scales, qzeros = _cpu_args()
+    with pytest.raises(RuntimeError, match="qweight must be a CUDA tensor"):
+        XbitOps.dequant(qweight, scales, qzeros, 128, 4, 128, 0)
+    with pytest.raises(RuntimeError, match="input_a must be a CUDA tensor"):
+        XbitOps.gemv(torch.zeros(1, 128, dtype=torch.float16), qweight, scales, qzeros, 128, 4, 128, 0)
+
+
+def test_module_surface_matches_reference_registration():
+    import inspect
+
+    import XbitOps
+
+    assert sorted(XbitOps.__all__) == ["dequant", "gemv"]
+    assert list(inspect.signature(XbitOps.dequant).parameters) == ["qweight", "scales", "qzeros", "groupsize", "bits", "in_features", "add_zero_bias"]
+    assert list(inspect.signature(XbitOps.gemv).parameters) == ["input_a", "qweight", "scales", "qzeros", "groupsize", "bits", "in_features", "add_zero_bias"]
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure; the shipped path must not reach it."""
+    for pkg in ("xbitops_amd", "XbitOps"):
+        for dirpath, _dirs, files in os.walk(os.path.join(ROOT, pkg)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                    text = open(os.path.join(dirpath, fn)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, fn)
+                    assert "xbit_oracle" not in text and "libxbit_ref" not in text, os.path.join(dirpath, fn)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from xbitops_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.XbitLibraryError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Kernel-duration sweep on the GPU box: GEMV launch-shape variants (4-bit), every bit-width, the
+batch edge, and dequant.  Per-launch durations come from hipExtLaunchKernel start/stop events
+(xbit_profile_enable).  Prints one line per case:  name  avg/median/min us  GB/s(algorithmic)  %of 8 TB/s.
+
+    python tools/gemv_sweep.py [--variants 0,1,2] [--quick]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from xbitops_amd import _lib, synth  # noqa: E402
+
+COLD_BYTES = 512 << 20
+
+
+def measure(lib, fn, n=200, warm=10):
+    ms = ctypes.c_float()
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    lib.xbit_profile_enable(1)
+    vals = []
+    for i in range(n):
+        fn(warm + i)
+        _lib.check(lib.xbit_profile_last_ms(ctypes.byref(ms)), "profile")
+        vals.append(ms.value * 1e3)
+    lib.xbit_profile_enable(0)
+    vals.sort()
+    return sum(vals) / len(vals), vals[len(vals) // 2], vals[0]
+
+
+def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200):
+    nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
+    copies = (COLD_BYTES + nbytes - 1) // nbytes + 1 if cold else 1
+    base = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
+    act = torch.from_numpy(base.act).to(dev)
+    qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
+    sc = [torch.from_numpy(base.scales).to(dev).clone() for c in range(copies)]
+    qz = [torch.from_numpy(base.qzeros).to(dev).clone() for c in range(copies)]
+    out = torch.empty((m, n), dtype=torch.float16, device=dev)
+    sp = torch.cuda.current_stream(dev).cuda_stream
+
+    def fn(i):
+        c = i % copies
+        st = lib.xbit_gemv_f16(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp)
+        assert st == 0, st
+
+    avg, med, mn = measure(lib, fn, iters)
+    return nbytes, avg, med, mn
+
+
+def dequant_case(lib, dev, k, n, bits, g, iters=100):
+    nbytes = synth.dequant_bytes(k, n, bits, g)
+    copies = max(2, (COLD_BYTES + nbytes - 1) // nbytes + 1)
+    base = synth.make_problem(k, n, bits, g, m=1, seed=k + n + bits)
+    qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
+    sc = torch.from_numpy(base.scales).to(dev)
+    qz = torch.from_numpy(base.qzeros).to(dev)
+    outs = [torch.empty((k, n), dtype=torch.float16, device=dev) for _ in range(copies)]
+    sp = torch.cuda.current_stream(dev).cuda_stream
+
+    def fn(i):
+        c = i % copies
+        st = lib.xbit_dequant_f16(outs[c].data_ptr(), qw[c].data_ptr(), sc.data_ptr(), qz.data_ptr(), bits, g, k, n, 1, sp)
+        assert st == 0, st
+
+    avg, med, mn = measure(lib, fn, iters)
+    return nbytes, avg, med, mn
+
+
+def show(name, nbytes, avg, med, mn):
+    gbps = nbytes / (avg * 1e-6) / 1e9
+    print("%-44s avg %8.2f  med %8.2f  min %8.2f us   %8.1f GB/s  %5.1f%% of 8TB/s  (min: %.1f%%)" % (
+        name, avg, med, mn, gbps, gbps / 80.0, nbytes / (mn * 1e-6) / 1e9 / 80.0), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
+    print("device:", torch.cuda.get_device_name(0), flush=True)
+    for v in [int(x) for x in args.variants.split(",") if x != ""]:
+        raw.xbit_debug_set_gemv_variant(v)
+        show("gemv w4 4096x11008 m1 variant %d cold" % v, *gemv_case(lib, dev, 4096, 11008, 4, 128, 1, True))
+        show("gemv w4 4096x11008 m1 variant %d warm" % v, *gemv_case(lib, dev, 4096, 11008, 4, 128, 1, False))
+    raw.xbit_debug_set_gemv_variant(-1)
+    if args.quick:
+        return
+    show("gemv w4 8192x28672 m1 cold (cfg4, 1 GPU)", *gemv_case(lib, dev, 8192, 28672, 4, 128, 1, True, 60))
+    show("gemv w4 8192x3584 m1 cold (cfg4 shard /8)", *gemv_case(lib, dev, 8192, 3584, 4, 128, 1, True))
+    for bits in range(2, 9):
+        show("gemv w%d 4096x4096 m1 cold (cfg3)" % bits, *gemv_case(lib, dev, 4096, 4096, bits, 128, 1, True))
+    for m in (1, 4, 16):
+        show("gemv w3 4096x11008 m%d cold (cfg5)" % m, *gemv_case(lib, dev, 4096, 11008, 3, 128, m, True))
+    for m in (4, 16):
+        show("gemv w4 4096x11008 m%d cold" % m, *gemv_case(lib, dev, 4096, 11008, 4, 128, m, True))
+    for bits in range(2, 9):
+        show("dequant w%d 4096x4096 cold" % bits, *dequant_case(lib, dev, 4096, 4096, bits, 128))
+    show("dequant w4 4096x11008 cold", *dequant_case(lib, dev, 4096, 11008, 4, 128))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Build libxbitops_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake.
+
+    python -m xbitops_amd.build            # incremental
+    python -m xbitops_amd.build --force    # rebuild everything
+    python -m xbitops_amd.build --asm      # also keep .s files under xbitops_amd/csrc/_obj/
+
+hipcc cross-compiles for gfx950 without a GPU present, so this runs in the build container; the
+resulting .so travels to the GPU box with the working tree (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libxbitops_hip.so")
+SOURCES = ["xbit_capi.hip", "xbit_dequant.hip", "xbit_gemv.hip"]
+HEADERS = ["xbit_device.h", "xbit_host.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+            "--offload-arch=" + ARCH]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the xbitops HIP library cannot be built on this machine")
+    return exe
+
+
+def _newest_input() -> float:
+    paths = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def is_current() -> bool:
+    return os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_input()
+
+
+def _compile(src: str, keep_asm: bool) -> str:
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    cmd = [hipcc()] + CXXFLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if keep_asm:
+        cmd += ["-save-temps=obj"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+    if not force and not keep_asm and is_current():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(lambda s: _compile(s, keep_asm), SOURCES))
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    os.replace(LIB + ".tmp", LIB)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, keep_asm="--asm" in sys.argv, verbose=True)

@@ -1,0 +1,148 @@
+// xbit_capi.hip — the extern "C" surface declared in include/xbitops_hip.h: argument checks,
+// status codes, the common launch function and the per-launch profiling aid.  No kernels here.
+#include <string.h>
+
+#include <atomic>
+
+#include "xbit_host.h"
+
+namespace xbit {
+
+ProfileState& profile_state() {
+  static thread_local ProfileState state;
+  return state;
+}
+
+int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, void** args) {
+  ProfileState& ps = profile_state();
+  hipError_t err;
+  if (ps.enabled) {
+    err = hipExtLaunchKernel(kernel, grid, block, args, 0, stream, ps.start, ps.stop, 0);
+    ps.pending = (err == hipSuccess);
+  } else {
+    err = hipLaunchKernel(kernel, grid, block, args, 0, stream);
+  }
+  if (err != hipSuccess) {
+    (void)hipGetLastError();  // clear the sticky error; the caller gets the code
+    return (int)err;
+  }
+  return XBIT_OK;
+}
+
+static std::atomic<int> g_gemv_variant{-1};
+int gemv_variant_override() { return g_gemv_variant.load(std::memory_order_relaxed); }
+
+static inline uint32_t packed_rows(uint32_t count, int bits) { return (uint32_t)(((uint64_t)count * (uint64_t)bits + 31u) / 32u); }
+
+static int check_common(const void* qweight, const void* scales, const void* qzeros, int bits, int groupsize, uint32_t k,
+                        uint32_t n) {
+  if (!qweight || !scales || !qzeros) return XBIT_ERR_NULL_POINTER;
+  if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
+  if (groupsize < 1) return XBIT_ERR_GROUPSIZE;
+  if (k == 0 || n == 0 || (n & 1u)) return XBIT_ERR_SHAPE;
+  if ((uint64_t)packed_rows(k, bits) * n >= (1ull << 32) || (uint64_t)k * n >= (1ull << 40)) return XBIT_ERR_SHAPE;
+  if (((uintptr_t)qweight & 3u) || ((uintptr_t)qzeros & 3u) || ((uintptr_t)scales & 1u)) return XBIT_ERR_ALIGNMENT;
+  return XBIT_OK;
+}
+
+}  // namespace xbit
+
+extern "C" {
+
+int xbit_abi_version(void) { return XBIT_ABI_VERSION; }
+
+const char* xbit_status_string(int status) {
+  switch (status) {
+    case XBIT_OK: return "success";
+    case XBIT_ERR_NULL_POINTER: return "xbitops: a required device pointer is NULL";
+    case XBIT_ERR_BITS: return "xbitops: bits must be in 2..8";
+    case XBIT_ERR_GROUPSIZE: return "xbitops: groupsize must be >= 1";
+    case XBIT_ERR_SHAPE: return "xbitops: invalid shape (m, k, n must be > 0, n even, sizes within 32-bit packed-word range)";
+    case XBIT_ERR_ALIGNMENT: return "xbitops: a device pointer is not aligned to its element size";
+    default: break;
+  }
+  if (status > 0) return hipGetErrorString((hipError_t)status);
+  return "xbitops: unknown status";
+}
+
+int xbit_dequant_f16(void* out, const void* qweight, const void* scales, const void* qzeros, int bits, int groupsize,
+                     uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream) {
+  if (!out) return XBIT_ERR_NULL_POINTER;
+  const int st = xbit::check_common(qweight, scales, qzeros, bits, groupsize, k, n);
+  if (st != XBIT_OK) return st;
+  if ((uintptr_t)out & 1u) return XBIT_ERR_ALIGNMENT;
+  xbit::DequantParams p;
+  p.out = static_cast<uint16_t*>(out);
+  p.qweight = static_cast<const uint32_t*>(qweight);
+  p.scales = static_cast<const uint16_t*>(scales);
+  p.qzeros = static_cast<const uint32_t*>(qzeros);
+  p.k = k;
+  p.n = n;
+  p.groupsize = (uint32_t)groupsize;
+  p.kw = xbit::packed_rows(k, bits);
+  p.groups = (k + (uint32_t)groupsize - 1) / (uint32_t)groupsize;
+  p.zw = xbit::packed_rows(n, bits);
+  p.bias = add_zero_bias;
+  p.kblocks = (k + 31) / 32;
+  return xbit::launch_dequant(p, bits, static_cast<hipStream_t>(hip_stream));
+}
+
+int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
+                  int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream) {
+  if (!out || !a) return XBIT_ERR_NULL_POINTER;
+  const int st = xbit::check_common(qweight, scales, qzeros, bits, groupsize, k, n);
+  if (st != XBIT_OK) return st;
+  if (m == 0 || (uint64_t)m * k >= (1ull << 40) || (uint64_t)m * n >= (1ull << 40)) return XBIT_ERR_SHAPE;
+  if (((uintptr_t)out & 1u) || ((uintptr_t)a & 1u)) return XBIT_ERR_ALIGNMENT;
+  xbit::GemvParams p;
+  p.out = static_cast<uint16_t*>(out);
+  p.a = static_cast<const uint16_t*>(a);
+  p.qweight = static_cast<const uint32_t*>(qweight);
+  p.scales = static_cast<const uint16_t*>(scales);
+  p.qzeros = static_cast<const uint32_t*>(qzeros);
+  p.m = m;
+  p.k = k;
+  p.n = n;
+  p.groupsize = (uint32_t)groupsize;
+  p.kw = xbit::packed_rows(k, bits);
+  p.groups = (k + (uint32_t)groupsize - 1) / (uint32_t)groupsize;
+  p.zw = xbit::packed_rows(n, bits);
+  p.bias = add_zero_bias;
+  p.tiles = 0;
+  p.batches = 0;
+  return xbit::launch_gemv(p, bits, static_cast<hipStream_t>(hip_stream));
+}
+
+int xbit_profile_enable(int on) {
+  xbit::ProfileState& ps = xbit::profile_state();
+  if (on && !ps.start) {
+    hipError_t err = hipEventCreate(&ps.start);
+    if (err == hipSuccess) err = hipEventCreate(&ps.stop);
+    if (err != hipSuccess) {
+      (void)hipGetLastError();
+      return (int)err;
+    }
+  }
+  ps.enabled = on != 0;
+  ps.pending = false;
+  return XBIT_OK;
+}
+
+int xbit_profile_last_ms(float* ms) {
+  if (!ms) return XBIT_ERR_NULL_POINTER;
+  xbit::ProfileState& ps = xbit::profile_state();
+  if (!ps.pending) return XBIT_ERR_SHAPE;
+  hipError_t err = hipEventSynchronize(ps.stop);
+  if (err == hipSuccess) err = hipEventElapsedTime(ms, ps.start, ps.stop);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)err;
+  }
+  return XBIT_OK;
+}
+
+/* Tuning hook, deliberately NOT in the public header: selects a GEMV launch-shape variant for
+ * sweeps (tools/gemv_sweep.py); -1 restores automatic selection. */
+void xbit_debug_set_gemv_variant(int v) { xbit::g_gemv_variant.store(v, std::memory_order_relaxed); }
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+// xbit_gemv.hip — fused low-bit dequant + fp16-activation GEMV for MI355X (gfx950, wave64).
+//
+// Replaces the reference's `gemv<scalar_t>` + `lauch_Gemv_kernel`
+// (/root/reference/src/cu/gemv_w4a16_pt.cu:35-145,149-173), which handles 4-bit / group 128 only
+// and aborts otherwise; this file covers bits 2..8, any group size, M >= 1.
+//
+// Shape of the computation (y[m,n] = sum_k a[m,k] * W[k,n], W dequantised on the fly):
+//   * bandwidth bound: ~0.5 B of packed weight per 2 flop at M = 1.  No MFMA — the job is to keep
+//     enough 16-byte loads in flight to saturate HBM and to spend < ~3 VALU ops per weight.
+//   * a lane owns 4 adjacent columns (one 16-byte load per packed row) and whole k-blocks
+//     (32 k = BITS packed rows, xbit_device.h); LN lanes side by side read LN*16 contiguous bytes
+//     of every packed row, the other 64/LN lanes of the wave ("k-lanes") and the NW waves of the
+//     workgroup take different k-batches of the same columns.  One workgroup therefore owns a
+//     4*LN-column tile over ALL of K: no cross-workgroup reduction, no atomics, no output memset
+//     (the reference zero-fills its output every call, dq_torch_ops.cc:71).
+//   * every lane issues all of its weight loads for a batch (UB k-blocks, up to 16 x 16 B) before
+//     it consumes any; scale / zero-point loads (one set per batch) ride along.
+//   * the activation slice a wave needs is staged once into LDS by that wave, already permuted into
+//     the pair order the unpacker produces (Unpack<BITS>::pair_k), and read back as broadcast
+//     ds_read_b128; only the staging wave reads it, so no workgroup barrier is needed before the
+//     main loop.
+//   * W is rebuilt in packed fp16 exactly as the reference dequant kernels do, then multiplied and
+//     accumulated in fp32 with v_dot2_f32_f16.  The sum over k-lanes is a wave shuffle tree, the
+//     sum over waves goes through LDS, the result is stored as fp16 (RNE).
+#include "xbit_device.h"
+#include "xbit_host.h"
+
+namespace xbit {
+
+namespace {
+
+template <int C>
+__device__ __forceinline__ uint32_t comp2(const uint2& v) {
+  if constexpr (C == 0) return v.x;
+  else return v.y;
+}
+
+// Streaming (read-once) 16-byte load of packed weights.
+template <bool NT>
+__device__ __forceinline__ uint4 load_w(const void* p) {
+  if constexpr (NT) return ld16_nt(p);
+  else return ld16(p);
+}
+
+template <int BITS, int UB, int LN, int NW, int MT, bool NT>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) gemv_tile_kernel(const GemvParams p) {
+  static_assert(LN == 4 || LN == 8 || LN == 16 || LN == 32 || LN == 64, "LN");
+  constexpr int LK = 64 / LN;           // k-lanes per wave
+  constexpr int T = LK * NW;            // k-lanes per workgroup
+  constexpr int CN = 4 * LN;            // columns per workgroup
+  constexpr int KLS = UB * 16 + 4;      // dwords per (row, k-lane) activation slot; +4 keeps the
+                                        // LK broadcast addresses of a ds_read_b128 on distinct banks
+  constexpr int ACT_DW = MT * LK * KLS;  // dwords of staged activations per wave
+  constexpr int NTASK = MT * LK * UB;    // 32-k staging tasks per wave and iteration
+  constexpr int ROUNDS = (NTASK + 63) / 64;
+
+  __shared__ __attribute__((aligned(16))) uint32_t s_act[NW * ACT_DW];
+  __shared__ __attribute__((aligned(16))) float s_red[NW * MT * CN];
+
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / LN, nl = lane % LN;
+  const uint32_t tile = xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t col = tile * CN + 4u * nl;
+  const bool col_ok = col < p.n;  // n % 4 == 0 on this path: a lane is all in or all out
+  const uint32_t m0 = blockIdx.y * MT;
+  uint32_t* const my_act = s_act + wv * ACT_DW;
+
+  const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
+  float acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+  for (uint32_t b0 = 0; b0 < p.batches; b0 += T) {
+    const uint32_t wb = b0 + wv * LK;  // first batch of this wave in this sweep
+    const uint32_t bt = wb + kl;       // this lane's batch
+    const bool active = col_ok && bt < p.batches;
+
+    // (1) activation slice of this wave: issue the global loads first (they are the oldest entries
+    //     of the vmcnt queue, so waiting for them does not wait for the weights).  Loads are
+    //     unconditional from clamped addresses — straight-line code lets the compiler count vmcnt
+    //     exactly — and out-of-range chunks are zeroed afterwards (k >= K must contribute 0).
+    uint4 hraw[ROUNDS][4];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int s = (lane + 64 * r) % NTASK;  // NTASK < 64: the upper lanes repeat the lower ones' task
+      const int mi = s / (LK * UB), blk = s % (LK * UB);
+      const uint32_t k0 = (wb * UB + blk) * 32u;
+      const uint32_t row = m0 + mi < p.m ? m0 + mi : p.m - 1;
+      const uint16_t* src = p.a + (size_t)row * p.k;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t kq = k0 + 8u * q;
+        hraw[r][q] = ld16(src + (kq < p.k ? kq : 0u));  // k % 8 == 0 on this path
+      }
+    }
+
+    // (2) scale and zero-point of the batch's group (one group per batch on this path).  An
+    //     inactive lane gets scale 0, which makes every weight it rebuilds exactly 0.
+    const uint32_t bt_c = bt < p.batches ? bt : p.batches - 1;
+    const uint32_t col_c = col_ok ? col : 0u;
+    uint32_t gi = (bt_c * (uint32_t)(UB * 32)) / p.groupsize;
+    gi = gi < p.groups ? gi : p.groups - 1;
+    uint2 sraw = *reinterpret_cast<const uint2*>(p.scales + (size_t)gi * p.n + col_c);
+    const uint32_t zwin = zero_window4<BITS>(p.qzeros + (size_t)gi * p.zw, col_c, p.zw);
+    if (!active) sraw = make_uint2(0, 0);
+
+    // (3) all packed-weight loads of this lane's batch (rows past the end are clamped: their
+    //     k-values are >= K, where the staged activation is zero)
+    uint4 w[UB][BITS];
+#pragma unroll
+    for (int j = 0; j < UB; ++j)
+#pragma unroll
+      for (int i = 0; i < BITS; ++i) {
+        const uint32_t row = (bt_c * UB + j) * BITS + i;
+        w[j][i] = load_w<NT>(p.qweight + (size_t)(row < p.kw ? row : p.kw - 1) * p.n + col_c);
+      }
+    // Pin the issue order act -> scale/zero -> weights: every wait below then lets all younger
+    // loads stay in flight (vmcnt counts in order).  Without this the scheduler interleaves the
+    // loads with their consumers and parks half the weight loads behind a wait.
+    __builtin_amdgcn_sched_barrier(0);
+
+    // (4) permute the activation slice into pair order and park it in this wave's LDS region
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      // every lane stores (duplicates write identical data): a conditional here would let the
+      // compiler sink the activation loads behind the weight loads and wait for all of them
+      const int s = (lane + 64 * r) % NTASK;
+      const int mi = s / (LK * UB), blk = s % (LK * UB);
+      const uint32_t k0 = (wb * UB + blk) * 32u;
+      const bool row_ok = m0 + mi < p.m;
+      uint32_t h[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = row_ok && k0 + 8u * q < p.k;
+        h[4 * q + 0] = ok ? hraw[r][q].x : 0u;
+        h[4 * q + 1] = ok ? hraw[r][q].y : 0u;
+        h[4 * q + 2] = ok ? hraw[r][q].z : 0u;
+        h[4 * q + 3] = ok ? hraw[r][q].w : 0u;
+      }
+      uint32_t* dst = my_act + (mi * LK + blk / UB) * KLS + (blk % UB) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pr = 4 * q + e;
+          const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
+          // bytes 0-1 <- half (klo&1) of h[klo/2]; bytes 2-3 <- half (khi&1) of h[khi/2]
+          const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) |
+                               ((uint32_t)(4 + 2 * (khi & 1)) << 16) | ((uint32_t)(5 + 2 * (khi & 1)) << 24);
+          o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+        }
+        *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};  // ds_write_b128
+      }
+    }
+    // the slice is produced and consumed by the same wave: LDS operations of one wave execute in
+    // order, so a wave-level fence (compiler ordering + lgkmcnt) is all that is needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // (5) per-column dequant constants: s2 = (s,s), nzs2 = (-(z+bias)*s) twice
+    half2_t s2[4], nzs2[4];
+    {
+      const uint32_t sr[4] = {sraw.x & 0xFFFFu, sraw.x >> 16, sraw.y & 0xFFFFu, sraw.y >> 16};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const _Float16 s = as_h((uint16_t)sr[c]);
+        const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + p.bias;
+        s2[c] = splat(s);
+        nzs2[c] = splat(neg_zero_times_scale(z, s));
+      }
+    }
+
+    // (6) unpack, dequantise, multiply-accumulate
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      u32x4_t av[MT][4];  // ds_read_b128, broadcast across the LN lanes that share kl
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[m][q] = *reinterpret_cast<const u32x4_t*>(my_act + (m * LK + kl) * KLS + j * 16 + 4 * q);
+
+      uint32_t wc[4][BITS];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < BITS; ++i) wc[c][i] = comp_rt(w[j][i], c);
+
+      // The four columns advance in lockstep, stage by stage, so that neighbouring instructions
+      // belong to independent chains (a packed-fp16 result consumed by the very next VALU
+      // instruction costs a wait state on gfx950).
+      static_for<16>([&](auto pr_c) {
+        constexpr int pr = decltype(pr_c)::value;
+        uint32_t Q[4];
+        half2_t wv2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Q[c] = Unpack<BITS>::template pair<pr>(wc[c], uk);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wv2[c] = dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[m][c] = __builtin_amdgcn_fdot2(wv2[c], as_h2(av[m][pr >> 2][pr & 3]), acc[m][c], false);
+      });
+    }
+    __builtin_amdgcn_wave_barrier();  // keep the next sweep's LDS writes behind these reads
+  }
+
+  // sum over the k-lanes of the wave (lanes that differ only in kl)
+#pragma unroll
+  for (int off = LN; off < 64; off <<= 1)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[m][c] += __shfl_xor(acc[m][c], off, 64);
+
+  // sum over waves through LDS, then one fp16 store per output element
+  if (kl == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      *reinterpret_cast<float4*>(s_red + (wv * MT + m) * CN + 4 * nl) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+  }
+  __syncthreads();
+  for (int e = tid; e < MT * CN; e += 64 * NW) {
+    const int m = e / CN, c = e % CN;
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) sum += s_red[(v * MT + m) * CN + c];
+    const uint32_t n_out = tile * CN + c, row = m0 + m;
+    if (n_out < p.n && row < p.m) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
+  }
+}
+
+// Fully general fallback: any n (even), any groupsize, any k.  One workgroup per output element
+// column-block of 1; slow (re-reads scales per element) but exact.  Used only for shapes the tiled
+// kernel does not take (n % 4 != 0 or groupsize % 32 != 0).
+__global__ void __launch_bounds__(256) gemv_generic_kernel(const GemvParams p, int bits) {
+  __shared__ float s_part[256];
+  const uint32_t col = blockIdx.x, row = blockIdx.y;
+  float acc = 0.f;
+  for (uint32_t k = threadIdx.x; k < p.k; k += 256) {
+    const uint32_t g = k / p.groupsize;
+    const _Float16 s = as_h(p.scales[(size_t)g * p.n + col]);
+    const uint32_t z = stream_field(p.qzeros + (size_t)g * p.zw, 1, col, bits, p.zw) + p.bias;
+    const uint32_t q = stream_field(p.qweight + col, p.n, k, bits, p.kw);
+    const _Float16 nzs = neg_zero_times_scale(z, s);
+    const _Float16 w = __builtin_elementwise_fma((_Float16)(float)(int)q, s, nzs);
+    acc += (float)as_h(p.a[(size_t)row * p.k + k]) * (float)w;
+  }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.out[(size_t)row * p.n + col] = as_u16((_Float16)s_part[0]);
+}
+
+template <int BITS, int UB, int LN, int NW, int MT, bool NT>
+int launch_tile(GemvParams p, hipStream_t stream) {
+  constexpr int CN = 4 * LN;
+  p.tiles = (p.n + CN - 1) / CN;
+  const uint32_t kblocks = (p.k + 31) / 32;
+  p.batches = (kblocks + UB - 1) / UB;
+  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * NW);
+  return launch(gemv_tile_kernel<BITS, UB, LN, NW, MT, NT>, grid, block, stream, p);
+}
+
+template <int BITS, int UB, int LN, int NW, bool NT>
+int launch_tile_m(const GemvParams& p, hipStream_t stream) {
+  if (p.m >= 4) return launch_tile<BITS, UB, LN, NW, 4, NT>(p, stream);
+  if (p.m >= 2) return launch_tile<BITS, UB, LN, NW, 2, NT>(p, stream);
+  return launch_tile<BITS, UB, LN, NW, 1, NT>(p, stream);
+}
+
+// k-blocks per batch: as many as fit 16 outstanding 16-byte loads per lane, within one group
+template <int BITS>
+constexpr int max_ub() {
+  return BITS <= 4 ? 4 : 2;
+}
+
+template <int BITS>
+int launch_bits(const GemvParams& p, hipStream_t stream) {
+  constexpr int UBMAX = max_ub<BITS>();
+#define XBIT_SHAPE(UB_, LN_, NW_, NT_) return launch_tile_m<BITS, UB_, LN_, NW_, NT_>(p, stream)
+  if (p.groupsize % (32u * UBMAX) == 0) {
+    if constexpr (BITS == 4) {  // tuning variants are only built for the headline bit-width
+      const int variant = gemv_variant_override();
+      switch (variant) {
+        case 1: XBIT_SHAPE(UBMAX, 8, 4, false);
+        case 2: XBIT_SHAPE(UBMAX, 16, 8, true);
+        case 3: XBIT_SHAPE(UBMAX, 16, 8, false);
+        case 4: XBIT_SHAPE(UBMAX, 8, 8, true);
+        case 5: XBIT_SHAPE(UBMAX, 16, 4, true);
+        case 6: XBIT_SHAPE(UBMAX, 4, 2, true);
+        case 7: XBIT_SHAPE(UBMAX, 4, 4, true);
+        default: break;
+      }
+    }
+    XBIT_SHAPE(UBMAX, 8, 4, true);
+  }
+  if constexpr (UBMAX > 2) {
+    if (p.groupsize % 64u == 0) { XBIT_SHAPE(2, 8, 4, true); }
+  }
+  XBIT_SHAPE(1, 8, 4, true);
+#undef XBIT_SHAPE
+}
+
+}  // namespace
+
+int launch_gemv(const GemvParams& p, int bits, hipStream_t stream) {
+  const bool aligned = ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 8 == 0) && ((uintptr_t)p.a % 16 == 0);
+  const bool tiled = (p.n % 4u == 0) && (p.k % 8u == 0) && (p.groupsize % 32u == 0) && aligned && p.m <= 65535u;
+  if (!tiled) {
+    if (p.m > 65535u) return XBIT_ERR_SHAPE;
+    dim3 grid(p.n, p.m), block(256);
+    return launch(gemv_generic_kernel, grid, block, stream, p, bits);
+  }
+  switch (bits) {
+    case 2: return launch_bits<2>(p, stream);
+    case 3: return launch_bits<3>(p, stream);
+    case 4: return launch_bits<4>(p, stream);
+    case 5: return launch_bits<5>(p, stream);
+    case 6: return launch_bits<6>(p, stream);
+    case 7: return launch_bits<7>(p, stream);
+    case 8: return launch_bits<8>(p, stream);
+    default: return XBIT_ERR_BITS;
+  }
+}
+
+}  // namespace xbit

@@ -1,0 +1,58 @@
+// xbit_host.h — host-side glue shared by the launchers: parameter blocks, status codes, and the
+// one function every launch goes through (so the optional per-launch event bracketing of
+// xbit_profile_enable applies uniformly).
+#pragma once
+
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xbitops_hip.h"
+
+namespace xbit {
+
+struct DequantParams {
+  uint16_t* out;            // fp16 [k, n]
+  const uint32_t* qweight;  // [kw, n]
+  const uint16_t* scales;   // fp16 [groups, n]
+  const uint32_t* qzeros;   // [groups, zw]
+  uint32_t k, n, groupsize, kw, groups, zw, bias, kblocks;
+};
+
+struct GemvParams {
+  uint16_t* out;            // fp16 [m, n]
+  const uint16_t* a;        // fp16 [m, k]
+  const uint32_t* qweight;  // [kw, n]
+  const uint16_t* scales;   // fp16 [groups, n]
+  const uint32_t* qzeros;   // [groups, zw]
+  uint32_t m, k, n, groupsize, kw, groups, zw, bias;
+  uint32_t tiles;    // column tiles (grid.x)
+  uint32_t batches;  // k-batches of UB k-blocks
+};
+
+// thread-local profiling state (xbit_profile_enable / xbit_profile_last_ms)
+struct ProfileState {
+  bool enabled = false;
+  bool pending = false;
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+ProfileState& profile_state();
+
+// Every launch goes through here; returns 0 or a positive hipError_t (never aborts).
+int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, void** args);
+
+// Launch `kernel<<<grid, block, 0, stream>>>(args...)`.
+template <typename... KArgs, typename... Args>
+int launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
+  void* ptrs[] = {static_cast<void*>(&args)...};
+  return launch_raw(reinterpret_cast<const void*>(kernel), grid, block, stream, ptrs);
+}
+
+int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
+int launch_gemv(const GemvParams& p, int bits, hipStream_t stream);
+
+// tuning hook (tools/ and bench sweeps only): <0 = automatic
+int gemv_variant_override();
+
+}  // namespace xbit

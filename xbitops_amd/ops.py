@@ -1,0 +1,132 @@
+"""The two XbitOps operators, host side (PyTorch-ROCm tensors in, HIP kernels underneath).
+
+Mirror of the reference's operator binding, /root/reference/src/dq_torch_ops.cc:
+
+* ``dequant(qweight, scales, qzeros, groupsize, bits, in_features, add_zero_bias)`` -> ``[K, N]``
+  (``dequant_any_bit``, dq_torch_ops.cc:23-44)
+* ``gemv(input_a, qweight, scales, qzeros, groupsize, bits, in_features, add_zero_bias)``
+  -> ``[B, N]`` or ``[B, S, N]``   (``op_gemv``, dq_torch_ops.cc:46-78)
+
+Same positional argument order, same shape/dtype rules, same validation (each check cites its
+line below).  Differences, all deliberate:
+
+* GEMV accepts bits 2..8 and any group size (the reference aborts unless bits==4 and
+  groupsize==128, gemv_w4a16_pt.cu:152-155);
+* both ops launch on torch's current stream of the tensors' device and restore the caller's
+  current device (the reference leaves ``cudaSetDevice`` sticky, dq_torch_ops.cc:32,58, and runs
+  GEMV on the legacy default stream, gemv_w4a16_pt.cu:162);
+* the output is ``torch.empty`` — the kernels write every element (reference: ``at::zeros``,
+  one extra memset per call, dq_torch_ops.cc:38,71);
+* errors raise ``RuntimeError``; nothing aborts the process.
+
+There is no CPU path: CPU tensors are rejected exactly as the reference's CHECK_CUDA does, and a
+missing native library is an import-time error (xbitops_amd._lib).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["dequant", "gemv"]
+
+
+def _check_input(t: torch.Tensor, name: str) -> None:
+    # CHECK_INPUT = CHECK_CUDA + CHECK_CONTIGUOUS (dq_torch_ops.cc:5-9)
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _check_common(qweight, scales, qzeros, groupsize: int, bits: int, in_features: int):
+    _check_input(qweight, "qweight")
+    _check_input(scales, "scales")
+    _check_input(qzeros, "qzeros")
+    if qweight.dim() != 2:  # dq_torch_ops.cc:28,53
+        raise RuntimeError("qweight must be 2-dimensional")
+    if groupsize < 16:  # :29,54
+        raise RuntimeError("groupsize must be >= 16")
+    if not 1 <= bits <= 8:  # :30,55
+        raise RuntimeError("bits must be >= 1 and <= 8")
+    if (in_features * bits + 31) // 32 != qweight.size(0):  # :31,56 (the reference's text is "in_features must be >= 1")
+        raise RuntimeError(
+            "in_features must be >= 1 and match qweight: ceil(in_features*bits/32) = %d but qweight has %d rows"
+            % ((in_features * bits + 31) // 32, qweight.size(0))
+        )
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:  # .data_ptr<int32_t>() (unpack_weight_2_to_7.cu:432)
+        raise RuntimeError("qweight and qzeros must be int32")
+    if scales.dtype not in (torch.float16, torch.bfloat16):  # bf16 is converted, :33-37; anything else fails data_ptr<half>
+        raise RuntimeError("scales must be float16 or bfloat16")
+    n = qweight.size(1)
+    groups = (in_features + groupsize - 1) // groupsize
+    # layout preconditions the reference indexes by but never checks
+    if scales.dim() != 2 or scales.size(0) < groups or scales.size(1) != n:
+        raise RuntimeError("scales must have shape [ceil(in_features/groupsize)=%d, N=%d], got %s" % (groups, n, tuple(scales.shape)))
+    zw = (n * bits + 31) // 32
+    if qzeros.dim() != 2 or qzeros.size(0) < groups or qzeros.size(1) != zw:
+        raise RuntimeError("qzeros must have shape [%d, ceil(N*bits/32)=%d], got %s" % (groups, zw, tuple(qzeros.shape)))
+    if qzeros.device != qweight.device or scales.device != qweight.device:
+        raise RuntimeError("qweight, scales and qzeros must be on the same device")
+
+
+def add_zero_bias_check(v: int) -> int:
+    v = int(v)
+    if not 0 <= v <= 255:  # uint8_t parameter (dq_torch_ops.cc:24,48)
+        raise RuntimeError("add_zero_bias must fit in uint8")
+    return v
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dequant(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, groupsize: int, bits: int, in_features: int,
+            add_zero_bias: int) -> torch.Tensor:
+    """Dequantise ``qweight`` to ``W[in_features, N]`` (fp16, or bf16 when ``scales`` is bf16)."""
+    groupsize, bits, in_features = int(groupsize), int(bits), int(in_features)
+    bias = add_zero_bias_check(add_zero_bias)
+    _check_common(qweight, scales, qzeros, groupsize, bits, in_features)
+    lib = _lib.load()
+    ori_dtype = scales.dtype
+    f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales  # dq_torch_ops.cc:33-37
+    n = qweight.size(1)
+    with torch.cuda.device(qweight.device):
+        out = torch.empty((in_features, n), dtype=torch.float16, device=qweight.device)
+        st = lib.xbit_dequant_f16(out.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(), bits, groupsize,
+                                  in_features, n, bias, _stream_ptr(qweight.device))
+    _lib.check(st, "XbitOps.dequant")
+    return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :40-42
+
+
+def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, groupsize: int, bits: int,
+         in_features: int, add_zero_bias: int) -> torch.Tensor:
+    """``input_a[B, K]`` or ``[B, S, K]`` (fp16) times the dequantised weight -> ``[B, (S,) N]``."""
+    groupsize, bits, in_features = int(groupsize), int(bits), int(in_features)
+    bias = add_zero_bias_check(add_zero_bias)
+    _check_input(input_a, "input_a")
+    _check_common(qweight, scales, qzeros, groupsize, bits, in_features)
+    if qweight.device != input_a.device:  # dq_torch_ops.cc:57
+        raise RuntimeError("input and weight must be on the same device")
+    if input_a.dtype != torch.float16:  # a_fp16.data_ptr<half>() throws otherwise (gemv_w4a16_pt.cu:163)
+        raise RuntimeError("input_a must be float16")
+    if input_a.dim() not in (2, 3) or input_a.size(-1) != in_features:
+        raise RuntimeError("input_a must be [B, in_features] or [B, S, in_features], got %s" % (tuple(input_a.shape),))
+    lib = _lib.load()
+    n = qweight.size(1)
+    shape = [input_a.size(0), n]  # dq_torch_ops.cc:59-64
+    mat_m = input_a.size(0)
+    if input_a.dim() > 2:
+        shape.insert(1, input_a.size(1))
+        mat_m *= input_a.size(1)
+    ori_dtype = scales.dtype
+    f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales  # :65-69
+    with torch.cuda.device(qweight.device):
+        out = torch.empty(shape, dtype=torch.float16, device=qweight.device)
+        if mat_m > 0:
+            st = lib.xbit_gemv_f16(out.data_ptr(), input_a.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(),
+                                   bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(qweight.device))
+            _lib.check(st, "XbitOps.gemv")
+    return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :74-76
