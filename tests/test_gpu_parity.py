@@ -61,10 +61,11 @@ def assert_gemv_close(y, y_ref, what=""):
     bad = err > tol
     assert not bad.any(), "%s: %d/%d outside 1e-3 rel; worst err %.3e at ref %.4f" % (
         what, bad.sum(), bad.size, err.max(), rf.flat[err.argmax()])
-    # with exact W and fp32 accumulation the result is the oracle's up to the last fp16 bit
+    # with exact W and fp32 accumulation the result is the oracle's up to the last fp16 bit, except
+    # where the sum cancels to ~0 and fp32 accumulation noise (~1e-6 absolute) exceeds an fp16 ulp
     ulp = np.abs(_bits(y).astype(np.int32) - _bits(y_ref).astype(np.int32))
     same_sign = (_bits(y) >> 15) == (_bits(y_ref) >> 15)
-    assert (ulp[same_sign] <= 1).mean() > 0.999, what
+    assert (((ulp <= 1) & same_sign) | (err <= 4e-6)).all(), what
 
 
 def test_native_library_is_what_runs(cuda_device):

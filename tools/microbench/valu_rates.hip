@@ -1,0 +1,132 @@
+// valu_rates.hip — issue cost (shader cycles per wave-instruction) of the VALU / MFMA ops the GEMV
+// kernel is built from, at 1, 2 and 4 waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3.
+// Each test issues 16 independent instructions per loop iteration (no dependent chains shorter
+// than 16), timed with s_memtime around the loop; prints median cycles / instruction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <algorithm>
+#include <vector>
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <int OP>
+__global__ void __launch_bounds__(1024) rate(uint64_t* out, int iters, uint32_t seed) {
+  float acc[16];
+  uint32_t u[16];
+  f2 p2[16];
+  f4 c4[4];
+  for (int i = 0; i < 16; ++i) { acc[i] = (float)i; u[i] = seed * (i + 1) + threadIdx.x; p2[i] = f2{(float)i, 1.f}; }
+  for (int i = 0; i < 4; ++i) c4[i] = f4{0, 0, 0, 0};
+  uint32_t a = seed + threadIdx.x, b = 0x3c003c00u, m = 0x000f000fu, g = 0x64006400u;
+  h8 fa, fb;
+  for (int i = 0; i < 8; ++i) { fa[i] = (_Float16)(float)(threadIdx.x & 7); fb[i] = (_Float16)1.0f; }
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(g));
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (OP == 0) {
+#define X(i) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 1) {
+#define X(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(u[i]) : "v"(b), "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 2) {
+#define X(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "s"(m), "v"(g));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 3) {
+#define X(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[i]) : "v"(a), "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 4) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2[i]) : "v"(p2[(i + 1) & 15]));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 5) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 6) {
+#define X(i) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u[i]) : "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 7) {  // MFMA 16x16x32 f16, 4 independent accumulators x4
+      for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 4; ++i) c4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c4[i], 0, 0, 0);
+    } else if constexpr (OP == 8) {  // interleaved: 13 VALU (and_or/pk_fma mix) per MFMA, like the planned GEMV body
+      for (int r = 0; r < 4; ++r) {
+        c4[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c4[r], 0, 0, 0);
+#define X(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(u[i]) : "v"(b), "v"(a));
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#undef X
+      }
+    } else if constexpr (OP == 9) {
+#define X(i) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(acc[i]) : "v"(u[i]));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 10) {
+#define X(i) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 11) {
+#define X(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(a), "v"(b));
+      REP16(X)
+#undef X
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  uint64_t t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += acc[i] + (float)u[i] + p2[i].x + p2[i].y;
+  for (int i = 0; i < 4; ++i) s += c4[i].x + c4[i].y + c4[i].z + c4[i].w;
+  if (s == 12345.678f) out[0] = 1;  // keep everything live
+  if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int OP>
+void run(const char* name, int instr_per_iter) {
+  const int iters = 2000;
+  uint64_t* d;
+  hipMalloc(&d, sizeof(uint64_t) * (1 + 256 * 16));
+  for (int waves_per_simd : {1, 2, 4}) {
+    const int threads = 64 * 4 * waves_per_simd;  // one workgroup per CU fills all 4 SIMDs evenly
+    const int blocks = 256;
+    hipMemset(d, 0, sizeof(uint64_t) * (1 + 256 * 16));
+    rate<OP><<<blocks, threads>>>(d, iters, 3);
+    hipDeviceSynchronize();
+    std::vector<uint64_t> h(1 + blocks * threads / 64);
+    hipMemcpy(h.data(), d, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    std::vector<uint64_t> v(h.begin() + 1, h.end());
+    std::sort(v.begin(), v.end());
+    double cyc = (double)v[v.size() / 2] / ((double)iters * instr_per_iter);
+    // s_memtime ticks at a fixed 100 MHz on gfx9; convert with the measured ratio below
+    printf("%-34s waves/SIMD=%d  ticks/instr(median wave)=%.4f  per-SIMD ticks per instr=%.4f\n", name, waves_per_simd, cyc,
+           cyc / waves_per_simd);
+  }
+  hipFree(d);
+}
+
+int main() {
+  printf("note: s_memtime counts REFCLK (100 MHz) ticks on this target if ticks/instr << 1; see clock calibration line\n");
+  run<5>("v_fma_f32", 16);
+  run<0>("v_dot2c_f32_f16", 16);
+  run<10>("v_dot2_f32_f16 (VOP3P)", 16);
+  run<1>("v_pk_fma_f16", 16);
+  run<6>("v_pk_add_f16", 16);
+  run<2>("v_and_or_b32", 16);
+  run<11>("v_perm_b32", 16);
+  run<3>("v_fma_mix_f32", 16);
+  run<4>("v_pk_fma_f32", 16);
+  run<9>("v_cvt_f32_f16", 16);
+  run<7>("v_mfma_f32_16x16x32_f16", 16);
+  run<8>("mfma + 13 pk_fma interleaved (x4)", 56);
+  return 0;
+}

@@ -312,9 +312,17 @@ int launch_bits(const GemvParams& p, hipStream_t stream) {
 }  // namespace
 
 int launch_gemv(const GemvParams& p, int bits, hipStream_t stream) {
-  const bool aligned = ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 8 == 0) && ((uintptr_t)p.a % 16 == 0);
-  const bool tiled = (p.n % 4u == 0) && (p.k % 8u == 0) && (p.groupsize % 32u == 0) && aligned && p.m <= 65535u;
-  if (!tiled) {
+  if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
+  if (p.m > 65535u * 16u) return XBIT_ERR_SHAPE;
+  const int variant = gemv_variant_override();
+  const bool k_ok = (p.k % 8u == 0) && (p.groupsize % 32u == 0) && ((uintptr_t)p.a % 16 == 0);
+  // production path: MFMA kernel, any even n
+  const bool mfma_ok = k_ok && ((uintptr_t)p.qweight % 8 == 0) && ((uintptr_t)p.scales % 4 == 0);
+  if (mfma_ok && !(variant >= 0 && variant < 10)) return launch_gemv_mfma(p, bits, stream, variant);
+  // VALU-only (v_dot2c) kernel: kept for A/B measurements (variants 0..9)
+  const bool dot2_ok = k_ok && (p.n % 4u == 0) && ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 8 == 0) &&
+                       p.m <= 65535u;
+  if (!dot2_ok || variant < 0) {
     if (p.m > 65535u) return XBIT_ERR_SHAPE;
     dim3 grid(p.n, p.m), block(256);
     return launch(gemv_generic_kernel, grid, block, stream, p, bits);

@@ -50,7 +50,8 @@ int launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, 
 }
 
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
-int launch_gemv(const GemvParams& p, int bits, hipStream_t stream);
+int launch_gemv(const GemvParams& p, int bits, hipStream_t stream);                        // dispatcher (xbit_gemv.hip)
+int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int variant);     // xbit_gemv_mfma.hip
 
 // tuning hook (tools/ and bench sweeps only): <0 = automatic
 int gemv_variant_override();
