@@ -244,7 +244,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "gemv_tile_kernel<4,...>", "avg_kernel_us": round(cold_avg * 1e3, 3),
+                "kernel": "gemv_mfma_kernel<4,...>", "avg_kernel_us": round(cold_avg * 1e3, 3),
                 "median_kernel_us": round(cold_sorted[len(cold_sorted) // 2] * 1e3, 3), "min_kernel_us": round(cold_sorted[0] * 1e3, 3),
                 "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch",
                 "warm_cache_avg_kernel_us": round(warm_avg * 1e3, 3), "warm_cache_gbps": round(nbytes / (warm_avg * 1e-3) / 1e9, 2),

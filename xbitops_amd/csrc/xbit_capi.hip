@@ -30,7 +30,9 @@ int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, vo
 }
 
 static std::atomic<int> g_gemv_variant{-1};
+static std::atomic<uint64_t*> g_gemv_trace{nullptr};
 int gemv_variant_override() { return g_gemv_variant.load(std::memory_order_relaxed); }
+uint64_t* gemv_trace_buffer() { return g_gemv_trace.load(std::memory_order_relaxed); }
 
 static inline uint32_t packed_rows(uint32_t count, int bits) { return (uint32_t)(((uint64_t)count * (uint64_t)bits + 31u) / 32u); }
 
@@ -110,6 +112,7 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
   p.bias = add_zero_bias;
   p.tiles = 0;
   p.batches = 0;
+  p.trace = xbit::gemv_trace_buffer();
   return xbit::launch_gemv(p, bits, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -144,5 +147,7 @@ int xbit_profile_last_ms(float* ms) {
 /* Tuning hook, deliberately NOT in the public header: selects a GEMV launch-shape variant for
  * sweeps (tools/gemv_sweep.py); -1 restores automatic selection. */
 void xbit_debug_set_gemv_variant(int v) { xbit::g_gemv_variant.store(v, std::memory_order_relaxed); }
+/* Device buffer (8 x uint64 per wave) that the stamped measurement build (variants 41+) fills. */
+void xbit_debug_set_gemv_trace(void* device_buffer) { xbit::g_gemv_trace.store(static_cast<uint64_t*>(device_buffer), std::memory_order_relaxed); }
 
 }  // extern "C"

@@ -317,7 +317,8 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream) {
   const int variant = gemv_variant_override();
   const bool k_ok = (p.k % 8u == 0) && (p.groupsize % 32u == 0) && ((uintptr_t)p.a % 16 == 0);
   // production path: MFMA kernel, any even n
-  const bool mfma_ok = k_ok && ((uintptr_t)p.qweight % 8 == 0) && ((uintptr_t)p.scales % 4 == 0);
+  const bool small = ((uint64_t)p.kw * p.n * 4u < (1ull << 31)) && ((uint64_t)p.m * p.k * 2u < (1ull << 31));
+  const bool mfma_ok = k_ok && small && ((uintptr_t)p.qweight % 4 == 0);
   if (mfma_ok && !(variant >= 0 && variant < 10)) return launch_gemv_mfma(p, bits, stream, variant);
   // VALU-only (v_dot2c) kernel: kept for A/B measurements (variants 0..9)
   const bool dot2_ok = k_ok && (p.n % 4u == 0) && ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 8 == 0) &&

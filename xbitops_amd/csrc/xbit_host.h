@@ -28,6 +28,7 @@ struct GemvParams {
   uint32_t m, k, n, groupsize, kw, groups, zw, bias;
   uint32_t tiles;    // column tiles (grid.x)
   uint32_t batches;  // k-batches of UB k-blocks
+  uint64_t* trace;   // measurement builds only: per-wave s_memrealtime stamps (else nullptr)
 };
 
 // thread-local profiling state (xbit_profile_enable / xbit_profile_last_ms)
@@ -53,7 +54,8 @@ int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
 int launch_gemv(const GemvParams& p, int bits, hipStream_t stream);                        // dispatcher (xbit_gemv.hip)
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int variant);     // xbit_gemv_mfma.hip
 
-// tuning hook (tools/ and bench sweeps only): <0 = automatic
+// tuning hooks (tools/ only): variant < 0 = automatic; trace buffer for the stamped build
 int gemv_variant_override();
+uint64_t* gemv_trace_buffer();
 
 }  // namespace xbit
