@@ -63,6 +63,7 @@ def cpu_baseline(seconds: float, nbytes: int):
     import oracle
     from xbitops_amd import synth
 
+    oracle.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box grants a 16-CPU share per GPU
     p = synth.make_problem(K_IN, N_OUT, BITS, GROUP, m=BATCH, seed=7)
     oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, GROUP, BITS, K_IN, 1)  # warm (page in, spin up threads)
     reps, t0 = 0, time.perf_counter()
@@ -187,7 +188,7 @@ def main():
         run_steps(W, K)
         if comm is not None:
             # leftover partial bucket, then join the side stream
-            if K % bucket and world > 1:
+            if (W + K) % bucket and world > 1:
                 gather_bucket((W + K) // bucket)
             compute.wait_stream(comm)
     torch.cuda.synchronize()

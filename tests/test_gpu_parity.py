@@ -215,3 +215,22 @@ def test_ops_run_on_current_stream_and_keep_device(cuda_device):
     s.synchronize()
     assert torch.equal(y, y_ref)
     assert torch.cuda.current_device() == cuda_device.index
+
+
+def test_sharded_wrapper_single_rank_uses_hip_op(cuda_device):
+    """world size 1: ShardedGemv is the plain HIP op (the multi-rank logic is covered on gloo)."""
+    from xbitops_amd import sharded
+
+    p = synth.make_problem(2048, 128, 4, 128, m=2, seed=21)
+    a, qw, sc, qz = to_dev(p, cuda_device)
+    op = sharded.ShardedGemv(qw, sc, qz, 128, 4, 2048, 1)
+    y = op(a)
+    torch.cuda.synchronize()
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, 2048, 1)
+    assert_gemv_close(y.cpu().numpy(), y_ref, "sharded world=1")
+    # a column shard computed on the GPU equals the matching slice of the full result
+    qw0, sc0, qz0 = sharded.shard_columns(qw, sc, qz, 4, 2, 1)
+    import XbitOps
+
+    y1 = XbitOps.gemv(a, qw0, sc0, qz0, 128, 4, 2048, 1)
+    assert torch.equal(y1, y[:, 64:128])
