@@ -82,6 +82,23 @@ def cpu_baseline(seconds: float, nbytes: int):
     }
 
 
+def pmc_traffic(workload_key: str):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE with
+    the gfx950 x2 correction + WRITE_SIZE; collected offline — counters cannot be read in-process).
+    Returns None when no record matches this workload."""
+    best = None
+    for root, _dirs, files in os.walk(os.path.join(ROOT, "profiles")):
+        if "pmc_traffic.json" in files:
+            try:
+                with open(os.path.join(root, "pmc_traffic.json")) as f:
+                    rec = json.load(f)
+                if rec.get("workload") == workload_key:
+                    best = (os.path.relpath(os.path.join(root, "pmc_traffic.json"), ROOT), rec)
+            except (OSError, ValueError):
+                pass
+    return best
+
+
 def main():
     args = parse_args()
     import torch
@@ -223,6 +240,7 @@ def main():
     if rank == 0:
         achieved = nbytes / (cold_avg * 1e-3) / 1e9
         value = world * nbytes * K / dt / 1e9
+        traffic = pmc_traffic("A16W4 GEMV in=%d out=%d group=%d batch=%d" % (K_IN, N_OUT, GROUP, BATCH))
         rec = {
             "metric": "A16W4 GEMV GB/s at 4096x11008 g128 batch=1 (algorithmic bytes / time; cold HBM)",
             "value": round(value, 2),
@@ -244,7 +262,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic[1]["traffic_bytes_per_launch"] if traffic else None,
+                "traffic_source": (traffic[0] + ": rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, bytes per launch") if traffic else None,
+                "algorithmic_bytes": nbytes,
                 "kernel": "gemv_mfma_kernel<4,...>", "avg_kernel_us": round(cold_avg * 1e3, 3),
                 "median_kernel_us": round(cold_sorted[len(cold_sorted) // 2] * 1e3, 3), "min_kernel_us": round(cold_sorted[0] * 1e3, 3),
                 "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch",
