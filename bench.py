@@ -115,11 +115,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for the 1-GPU rehearsal below
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # nccl == RCCL on ROCm.  XBIT_BENCH_BACKEND=gloo rehearses the multi-rank control flow with
+        # several ranks on ONE GPU (RCCL refuses two ranks per device); never used for reported numbers.
+        backend = os.environ.get("XBIT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     lib = _lib.load()  # raises if the HIP library is missing
     raw = ctypes.CDLL(_lib.LIB_PATH)
@@ -258,7 +265,9 @@ def main():
                 "workload": "A16W4 GEMV in=4096 out=11008 group=128 batch=1 (Llama-7B FFN, BASELINE.json configs[1]) per GPU",
                 "bits": BITS, "groupsize": GROUP, "batch": BATCH, "algorithmic_bytes_per_step": nbytes,
                 "weight_copies_rotated": copies, "timed_region": "hipGraph replay of K launches" if graph is not None else "eager launches",
-                "parallelism": "column shards x%d + bucketed RCCL all-gather (bucket %d) on a side stream" % (world, bucket) if world > 1 else "single GPU",
+                "parallelism": "column shards x%d + bucketed %s all-gather (bucket %d) on a side stream" % (
+                    world, "RCCL" if os.environ.get("XBIT_BENCH_BACKEND", "nccl") == "nccl" else os.environ["XBIT_BENCH_BACKEND"], bucket)
+                if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

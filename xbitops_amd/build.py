@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libxbitops_hip.so")
 SOURCES = ["xbit_capi.hip", "xbit_dequant.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip"]
-HEADERS = ["xbit_device.h", "xbit_host.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
+HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
             "--offload-arch=" + ARCH]

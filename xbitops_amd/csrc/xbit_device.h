@@ -18,6 +18,8 @@
 
 #include <type_traits>
 
+#include "xbit_unpack_gen.h"
+
 namespace xbit {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -89,16 +91,16 @@ __device__ __forceinline__ uint32_t opaque_vgpr(uint32_t v) {
   return r;
 }
 
-// How the 32 k-values of a k-block are paired into 16 packed-fp16 operands.
-//   2/4/8 bit: the two fields 16 bits apart in one word, so ONE mask yields both halves;
-//   3/5/6/7:   neighbours (2p, 2p+1).
-// `pair_k(p, h)` is the k index (0..31) that sits in half h (0 = low) of pair p; the activation
-// vector is staged into LDS in exactly this order.
-//
-// For 2/4/8 bit a field need not be shifted down to bit 0 before the exponent splice: a field at
-// bit e <= 10 - BITS of its half word gives (x & (mask << e)) | 0x6400 = 1024 + q * 2^e, and
-// fma(that, 2^-e, -1024 * 2^-e) = q exactly.  `pair_exp(p)` is that e; one shift per word (by
-// kShiftStep bits) brings the upper fields into range.
+// How the 32 k-values of a k-block are paired into 16 packed-fp16 operands, and how a pair is
+// extracted with ONE v_and_or_b32:  (X & (mask << e)) | 0x64006400 = (1024 + q_lo*2^e, 1024 + q_hi*2^e)
+// whenever the two fields sit at the same bit offset e <= 10 - BITS of the two 16-bit halves of X.
+// The conversion back is exact: fma(1024 + q*2^e, 2^-e, -1024*2^-e) = q  (dequant_pair<E>).
+//   2/4/8 bit: X is the packed word itself (fields 16 bits apart pair up), shifted once per word to
+//              bring the upper fields into the mantissa range;
+//   3/5/6/7:   fields k and k+8 start exactly BITS bytes apart, so X is one v_perm_b32 of two
+//              byte-aligned 16-bit windows (generated plans: xbit_unpack_gen.h, tools/gen_unpack.py).
+// `pair_k(p, h)` is the k index (0..31) in half h (0 = low) of pair p; pairs never leave a chunk of
+// kChunkK consecutive k, and the activation vector is staged into LDS in exactly this pair order.
 template <int BITS>
 struct Unpack {
   static constexpr bool kPow2 = (BITS == 2 || BITS == 4 || BITS == 8);
@@ -107,22 +109,32 @@ struct Unpack {
   static constexpr uint32_t kMask = (1u << BITS) - 1u;
   static constexpr int kFree = !kPow2 ? 1 : (10 / BITS < kPerHalf ? 10 / BITS : kPerHalf);  // fields usable per view
   static constexpr int kShiftStep = kFree * BITS;
+  static constexpr int kChunkK = (kPow2 && BITS != 2) ? 8 : 16;  // span of k inside which pairs are formed
+  static constexpr int kMaskN = 11 - BITS;                       // admissible field offsets e = 0 .. 10 - BITS
 
   __host__ __device__ static constexpr int pair_k(int p, int h) {
     if (kPow2) return (p / kPerHalf) * kPerWord + (p % kPerHalf) + h * kPerHalf;
-    return 2 * p + h;
+    return 16 * (p / 8) + (p % 8) + 8 * h;
   }
-  __host__ __device__ static constexpr int pair_exp(int p) { return kPow2 ? ((p % kPerHalf) % kFree) * BITS : 0; }
+  __host__ __device__ static constexpr int pair_exp(int p) {
+    if constexpr (kPow2) return ((p % kPerHalf) % kFree) * BITS;
+    else return OddUnpack<BITS>::kExp[p];
+  }
+  // packed rows (of the k-block's BITS) that hold every field of MFMA octet `oct` (pairs 4*oct..4*oct+3)
+  __host__ __device__ static constexpr int rows_for_octet(int oct) {
+    if (kPow2) return ((oct + 1) * 8 * BITS + 31) / 32;
+    return ((oct / 2 + 1) * 16 * BITS + 31) / 32;
+  }
 
-  // Loop-invariant constants of pairs(): build once per kernel.
+  // Loop-invariant constants: build once per kernel.
   struct Consts {
     uint32_t magic;         // VGPR: 0x64006400
-    uint32_t mask[kFree];   // SGPRs: the field mask at each in-view position, both halves
+    uint32_t mask[kMaskN];  // SGPRs: (field mask << e) in both halves, e = index
   };
   __device__ __forceinline__ static Consts consts() {
     Consts k;
     k.magic = opaque_vgpr(kMagic1024x2);
-    static_for<kFree>([&](auto i) { k.mask[decltype(i)::value] = opaque_sgpr((kMask << (decltype(i)::value * BITS)) * 0x00010001u); });
+    static_for<kMaskN>([&](auto e) { k.mask[decltype(e)::value] = opaque_sgpr((kMask << decltype(e)::value) * 0x00010001u); });
     return k;
   }
 
@@ -132,9 +144,9 @@ struct Unpack {
     if constexpr (kPow2) {
       constexpr int c = P / kPerHalf, i = P % kPerHalf, view = i / kFree;
       const uint32_t x = view == 0 ? w[c] : (w[c] >> (view * kShiftStep));  // CSE'd across the pairs of a word
-      return (x & k.mask[i % kFree]) | k.magic;                             // v_and_or_b32
+      return (x & k.mask[(i % kFree) * BITS]) | k.magic;                    // v_and_or_b32
     } else {
-      return field<BITS>(w, 2 * P) | (field<BITS>(w, 2 * P + 1) << 16) | kMagic1024x2;
+      return OddUnpack<BITS>::template pair<P>(w, k);
     }
   }
 };

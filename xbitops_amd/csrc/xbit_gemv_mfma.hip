@@ -49,8 +49,8 @@ constexpr uint32_t kOob = 0x80000000u;  // a lane offset that is out of range fo
 template <int BITS, int UB, int LA>
 struct LoadSchedule {
   static constexpr int kTotal = UB * BITS;  // row loads per lane and sweep
-  // loads step s consumes: all rows of earlier blocks plus the words holding fields 0..8*(oct+1)-1
-  static constexpr int need(int s) { return (s / 4) * BITS + (((s % 4) + 1) * 8 * BITS + 31) / 32; }
+  // loads step s consumes: all rows of earlier blocks plus the rows holding the octet's pairs
+  static constexpr int need(int s) { return (s / 4) * BITS + Unpack<BITS>::rows_for_octet(s % 4); }
   // loads issued once step s's prefetch is out (LA == 0: everything up front)
   static constexpr int issued_before(int s) {
     if (LA == 0) return kTotal;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   // unpacker pairs fields: a packed word for 2/4/8 bit), 16*CPT bytes, one lane per task.  Every
   // VMEM instruction costs the CU's address pipeline the same whatever its width, so the slice is
   // fetched with as few wave-instructions as possible (one 16-byte load per wave at M = 1).
-  constexpr int CHK = (BITS == 2) ? 16 : 8;  // k per chunk
+  constexpr int CHK = Unpack<BITS>::kChunkK;  // k per chunk
   constexpr int CPT = CHK / 8;               // 16-byte loads / LDS stores per task
   constexpr int NTASK = MT * LK * UB * (32 / CHK);
   constexpr int ROUNDS = (NTASK + 63) / 64;
