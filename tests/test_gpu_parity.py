@@ -138,6 +138,41 @@ def test_gemv_all_bits(bits, cuda_device):
         assert_gemv_close(y, y_ref, "bits=%d k=%d n=%d g=%d m=%d bias=%d" % (bits, k, n, g, m, bias))
 
 
+@pytest.mark.parametrize("bits", [3, 4, 8])
+def test_gemv_row_counts_and_tile_widths(bits, cuda_device):
+    """Every rows-per-pass variant (1, 4, 8, 16, >16) and every tile width the launcher can pick
+    (8/12/16-byte loads), including column counts that end inside a tile."""
+    for m in (2, 3, 5, 8, 9, 16, 17, 33):
+        p = synth.make_problem(1024, 96, bits, 128, m=m, seed=bits * 31 + m)
+        y = run_gemv(p, 1, cuda_device)
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, 1024, 1, oracle.RNE)
+        assert_gemv_close(y, y_ref, "bits=%d m=%d" % (bits, m))
+    for k, n, m in ((256, 8192, 1), (512, 11008, 1), (512, 11008, 4), (256, 4096 + 64, 2), (8192, 50, 1), (8192 + 64, 130, 3)):
+        p = synth.make_problem(k, n, bits, 128, m=m, seed=bits * 37 + n)
+        y = run_gemv(p, 0, cuda_device)
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, k, 0, oracle.RNE)
+        assert_gemv_close(y, y_ref, "bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
+
+
+def test_gemv_w4_llama70b_ffn_shard_and_full(cuda_device):
+    """BASELINE.json config 4: the 8-GPU column shard (8192x3584) against the oracle, and the full
+    8192x28672 layer through a size-independent property: the result restricted to a column shard
+    equals the GEMV of that shard alone (columns are independent)."""
+    import XbitOps
+    from xbitops_amd import sharded
+
+    p = synth.make_problem(8192, 28672, 4, 128, m=1, seed=4)
+    a, qw, sc, qz = to_dev(p, cuda_device)
+    y_full = XbitOps.gemv(a, qw, sc, qz, 128, 4, 8192, 1)
+    for r in (0, 5, 7):
+        qw_r, sc_r, qz_r = sharded.shard_columns(qw, sc, qz, 4, 8, r)
+        y_r = XbitOps.gemv(a, qw_r, sc_r, qz_r, 128, 4, 8192, 1)
+        assert torch.equal(y_r, y_full[:, r * 3584:(r + 1) * 3584])
+    qw_r, sc_r, qz_r = sharded.shard_columns(p.qweight, p.scales, p.qzeros, 4, 8, 5)
+    y_ref = oracle.gemv(p.act, qw_r, sc_r, qz_r, 128, 4, 8192, 1, oracle.RNE)
+    assert_gemv_close(y_full[:, 5 * 3584:6 * 3584].cpu().numpy(), y_ref, "cfg4 shard 5")
+
+
 def test_gemv_w4_llama7b_ffn_full_size(cuda_device):
     """BASELINE.json config 2 at full size."""
     p = synth.make_problem(4096, 11008, 4, 128, m=1, seed=2)

@@ -20,8 +20,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libxbitops_hip.so")
-SOURCES = ["xbit_capi.hip", "xbit_dequant.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip"]
-HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
+SOURCES = ["xbit_capi.hip", "xbit_dequant.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip"] + ["xbit_gemv_mfma_b%d.hip" % b for b in range(2, 9)]
+HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", "xbit_gemv_mfma.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
             "--offload-arch=" + ARCH]
@@ -62,7 +62,7 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(lambda s: _compile(s, keep_asm), SOURCES))
     cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)

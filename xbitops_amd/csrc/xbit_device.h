@@ -57,14 +57,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// component c (0..3) of a uint4 with a compile-time index
-template <int C>
-__device__ __forceinline__ uint32_t comp(const uint4& v) {
-  if constexpr (C == 0) return v.x;
-  else if constexpr (C == 1) return v.y;
-  else if constexpr (C == 2) return v.z;
-  else return v.w;
-}
+// component c (0..3) of a uint4 (c is a compile-time constant after unrolling)
 __device__ __forceinline__ uint32_t comp_rt(const uint4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
 // Field `idx` (0..31, compile-time after unrolling) of the 32-field LSB-first stream w[0..BITS).

@@ -1,9 +1,12 @@
-// xbit_gemv.hip — fused low-bit dequant + fp16-activation GEMV for MI355X (gfx950, wave64).
+// xbit_gemv.hip — GEMV dispatcher (launch_gemv), the general fallback kernel, and the VALU-only
+// (v_dot2c_f32_f16) GEMV kept as the measured comparison point for the MFMA kernel in
+// xbit_gemv_mfma.hip (why the production kernel uses the matrix pipe).
 //
 // Replaces the reference's `gemv<scalar_t>` + `lauch_Gemv_kernel`
 // (/root/reference/src/cu/gemv_w4a16_pt.cu:35-145,149-173), which handles 4-bit / group 128 only
-// and aborts otherwise; this file covers bits 2..8, any group size, M >= 1.
+// and aborts otherwise; this library covers bits 2..8, any group size, M >= 1.
 //
+// The VALU-only kernel below:
 // Shape of the computation (y[m,n] = sum_k a[m,k] * W[k,n], W dequantised on the fly):
 //   * bandwidth bound: ~0.5 B of packed weight per 2 flop at M = 1.  No MFMA — the job is to keep
 //     enough 16-byte loads in flight to saturate HBM and to spend < ~3 VALU ops per weight.
@@ -28,12 +31,6 @@
 namespace xbit {
 
 namespace {
-
-template <int C>
-__device__ __forceinline__ uint32_t comp2(const uint2& v) {
-  if constexpr (C == 0) return v.x;
-  else return v.y;
-}
 
 // Streaming (read-once) 16-byte load of packed weights.
 template <bool NT>
@@ -287,7 +284,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream) {
   constexpr int UBMAX = max_ub<BITS>();
 #define XBIT_SHAPE(UB_, LN_, NW_, NT_) return launch_tile_m<BITS, UB_, LN_, NW_, NT_>(p, stream)
   if (p.groupsize % (32u * UBMAX) == 0) {
-    if constexpr (BITS == 4) {  // tuning variants are only built for the headline bit-width
+    {
       const int variant = gemv_variant_override();
       switch (variant) {
         case 1: XBIT_SHAPE(UBMAX, 8, 4, false);
@@ -320,24 +317,14 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream) {
   const bool small = ((uint64_t)p.kw * p.n * 4u < (1ull << 31)) && ((uint64_t)p.m * p.k * 2u < (1ull << 31));
   const bool mfma_ok = k_ok && small && ((uintptr_t)p.qweight % 4 == 0);
   if (mfma_ok && !(variant >= 0 && variant < 10)) return launch_gemv_mfma(p, bits, stream, variant);
-  // VALU-only (v_dot2c) kernel: kept for A/B measurements (variants 0..9)
-  const bool dot2_ok = k_ok && (p.n % 4u == 0) && ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 8 == 0) &&
-                       p.m <= 65535u;
-  if (!dot2_ok || variant < 0) {
-    if (p.m > 65535u) return XBIT_ERR_SHAPE;
-    dim3 grid(p.n, p.m), block(256);
-    return launch(gemv_generic_kernel, grid, block, stream, p, bits);
-  }
-  switch (bits) {
-    case 2: return launch_bits<2>(p, stream);
-    case 3: return launch_bits<3>(p, stream);
-    case 4: return launch_bits<4>(p, stream);
-    case 5: return launch_bits<5>(p, stream);
-    case 6: return launch_bits<6>(p, stream);
-    case 7: return launch_bits<7>(p, stream);
-    case 8: return launch_bits<8>(p, stream);
-    default: return XBIT_ERR_BITS;
-  }
+  // VALU-only (v_dot2c) kernel: 4-bit only, kept for A/B measurements (variants 0..9)
+  const bool dot2_ok = k_ok && bits == 4 && (p.n % 4u == 0) && ((uintptr_t)p.qweight % 16 == 0) &&
+                       ((uintptr_t)p.scales % 8 == 0) && p.m <= 65535u;
+  if (dot2_ok && variant >= 0 && variant < 10) return launch_bits<4>(p, stream);
+  // everything else: exact but slow
+  if (p.m > 65535u) return XBIT_ERR_SHAPE;
+  dim3 grid(p.n, p.m), block(256);
+  return launch(gemv_generic_kernel, grid, block, stream, p, bits);
 }
 
 }  // namespace xbit

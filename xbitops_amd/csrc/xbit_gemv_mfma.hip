@@ -1,481 +1,27 @@
-// xbit_gemv_mfma.hip — the production A16Wx GEMV / skinny-GEMM kernel (M = 1..16 per pass) for gfx950.
-//
-// Same decomposition as xbit_gemv.hip (a workgroup owns a column tile over all of K; lanes own
-// whole 32-k blocks; all packed-weight loads of a batch are issued before any is consumed; the
-// activation slice is staged per wave in LDS in the unpacker's pair order; W is rebuilt bit-exactly
-// in packed fp16), but the multiply-accumulate runs on the matrix pipe:
-//
-//   v_mfma_f32_16x16x32_f16:  D[16 x 16] += A[16 x 32] * B[32 x 16],  fp32 accumulate
-//     lane l supplies  B[k = 8*(l>>4) + j][col = l&15]  and  A[row = l&15][k = 8*(l>>4) + j], j < 8.
-//
-// Why a matrix instruction in a bandwidth-bound GEMV: measured on MI355X (tools/microbench/
-// valu_rates.hip, profiles/) every VALU op this kernel needs — v_and_or_b32, v_pk_add_f16,
-// v_pk_fma_f16 and also v_dot2c_f32_f16 — retires one wave-instruction per ~3.5 cycles per SIMD at
-// best (7 with one wave per SIMD).  With the dot product on the VALU (xbit_gemv.hip: 4.3 ops per
-// pair of weights) the unpack+MAC stream needs 2-3x the time HBM needs to deliver the weights.
-// Moving the MACs to the otherwise idle matrix pipe removes a quarter of the VALU stream, removes
-// the cross-lane shuffle reduction (the MFMA sums the four k-lane groups), and makes M = 2..16
-// rows cost the same as M = 1.  Nothing is reshaped: the "k" of the MFMA is simply 4 lane groups x
-// 8 consecutive fields of the k-block each lane already owns.
-//
-// Lane map (wave64): kq = lane >> 4 picks the k-batch (UB k-blocks) of this lane, nc = lane & 15 the
-// column group; a lane loads CPL adjacent columns (8 or 16 bytes) of each packed row of its
-// k-blocks.  MFMA step (block j, octet i, column c): B fragment = fields 8i..8i+7 (pair order) of
-// block j, column c, from every lane; A fragment = the matching 8 activations of row (nc % MT),
-// read from LDS as one broadcast ds_read_b128.  Output element: D[row][nc] of accumulator c is
-// y[m0 + row][tile*CN + nc*CPL + c].
-#include "xbit_device.h"
+// xbit_gemv_mfma.hip — bit-width dispatch for the MFMA GEMV.  The kernel template lives in
+// xbit_gemv_mfma.h and is instantiated once per bit-width in xbit_gemv_mfma_b{2..8}.hip so that the
+// seven widths compile in parallel.
 #include "xbit_host.h"
 
 namespace xbit {
 
-namespace {
-
-typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-typedef float f4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
-
-// Buffer descriptors give (a) a 32-bit per-lane byte offset plus a wave-uniform scalar offset, so
-// stepping to the next packed row costs no VALU instruction, (b) hardware range checking: a load
-// past the end of the tensor returns 0, which is exactly the neutral value wanted for edge rows.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-constexpr uint32_t kOob = 0x80000000u;  // a lane offset that is out of range for every tensor (< 2 GiB each)
-
-// Which row loads must be out before MFMA step s = (k-block s/4, octet s%4) of a sweep.
-template <int BITS, int UB, int LA>
-struct LoadSchedule {
-  static constexpr int kTotal = UB * BITS;  // row loads per lane and sweep
-  // loads step s consumes: all rows of earlier blocks plus the rows holding the octet's pairs
-  static constexpr int need(int s) { return (s / 4) * BITS + Unpack<BITS>::rows_for_octet(s % 4); }
-  // loads issued once step s's prefetch is out (LA == 0: everything up front)
-  static constexpr int issued_before(int s) {
-    if (LA == 0) return kTotal;
-    return need(s) + LA < kTotal ? need(s) + LA : kTotal;
-  }
-};
-
-// CPL adjacent packed words of one row (8 / 12 / 16 bytes per lane)
-template <int CPL, bool NT>
-struct RowLoad {
-  uint32_t v[CPL];
-  __device__ __forceinline__ void load(rsrc_t r, uint32_t voff, uint32_t soff) {
-    constexpr int aux = NT ? 2 : 0;  // nt: read-once stream
-    if constexpr (CPL == 2) {
-      const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux);
-      v[0] = t.x; v[1] = t.y;
-    } else if constexpr (CPL == 3) {
-      const u32x3_t t = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, aux);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z;
-    } else {
-      const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
-  }
-};
-
-// Template parameters
-//   BITS  weight width 2..8          UB   k-blocks per lane and sweep (UB*BITS row loads in flight)
-//   CPL   adjacent columns per lane: 2, 3 or 4 (8/12/16-byte loads; tile = NL*CPL columns).  Picked
-//         by the launcher so that the number of tiles sits just under a multiple of the CU count.
-//   NL    lanes side by side along N (16 or 8).  The MFMA tile has 16 column slots (lane & 15):
-//         with NL = 16 they are 16 column groups; with NL = 8 they are 8 column groups x 2 k-slots,
-//         kept apart by feeding their activations to row blocks 0-7 and 8-15 of the A operand:
-//         D[ks*8 + m][ks*8 + nl] is the sum over k-slot ks, the off-diagonal quadrants are don't-care.
-//   NW    waves per workgroup        MT   activation rows per pass (<= NL)
-//   NT    nontemporal weight loads   GUARD  false when the shape needs no edge handling at all
-//   ABLATE (measurement builds only): 1 = no weight loads (registers stand in), 2 = no
-//          unpack/dequant/MFMA (loaded words are xor-folded), 3 = both (all three: wrong results);
-//          8 = correct results plus per-wave s_memrealtime stamps written to p.trace
-//   LA   load lookahead in row loads (0 = issue the whole batch up front).  A wave issues in order,
-//        and the CU's memory pipeline back-pressures: a wave that queues all its loads first sits at
-//        the last load instruction until the queue drains and only then starts on data that came
-//        back long ago.  With LA > 0 the row loads are woven into the compute stream: before MFMA
-//        step s the loads needed by steps <= s + LA are issued, so a wave computes while its later
-//        rows are in flight and never holds more than LA + 1 queue slots.
-template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0>
-__global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) {
-  static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
-  static_assert(NL == 16 || NL == 8, "lanes along N");
-  constexpr int LK = 64 / NL;            // k-slots per wave
-  constexpr int RS = 16 / NL;            // k-slots sharing one MFMA k-quad (row split of the A tile)
-  constexpr int RB = 16 / RS;            // rows per row block
-  static_assert(MT == 1 || MT == 2 || MT == 4 || MT == 8 || MT == 16, "rows per pass");
-  static_assert(MT <= RB, "rows per pass exceed the row block");
-  constexpr int T = LK * NW;             // k-batches per workgroup sweep
-  constexpr int CN = NL * CPL;           // columns per workgroup
-  constexpr int KLS = UB * 16 + 4;       // dwords per (row, k-slot) activation slot (+4: bank spread)
-  constexpr int ACT_DW = MT * LK * KLS;  // staged activation dwords per wave
-  // Activation staging: a task is one chunk of CHK consecutive k (the span inside which the
-  // unpacker pairs fields: a packed word for 2/4/8 bit), 16*CPT bytes, one lane per task.  Every
-  // VMEM instruction costs the CU's address pipeline the same whatever its width, so the slice is
-  // fetched with as few wave-instructions as possible (one 16-byte load per wave at M = 1).
-  constexpr int CHK = Unpack<BITS>::kChunkK;  // k per chunk
-  constexpr int CPT = CHK / 8;               // 16-byte loads / LDS stores per task
-  constexpr int NTASK = MT * LK * UB * (32 / CHK);
-  constexpr int ROUNDS = (NTASK + 63) / 64;
-
-  __shared__ __attribute__((aligned(16))) uint32_t s_act[NW * ACT_DW];
-  __shared__ __attribute__((aligned(16))) float s_red[NW * RS * MT * CN];
-
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / NL, nl = lane % NL;
-  const uint32_t tile = xcd_tile(blockIdx.x, p.tiles);
-  const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
-  const bool col_ok = GUARD ? col < p.n : true;  // n % CPL == 0 is NOT required: stores are per column
-  const uint32_t m0 = blockIdx.y * MT;
-  uint32_t* const my_act = s_act + wv * ACT_DW;
-  const int arow = nl % MT;  // activation row this lane feeds to its row block of the A tile
-  const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
-  const uint32_t row_bytes = p.n * 4u;  // one packed row
-
-  const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
-  const rsrc_t r_s = make_rsrc(p.scales, p.groups * p.n * 2u);
-  const rsrc_t r_z = make_rsrc(p.qzeros, p.groups * p.zw * 4u);
-  const rsrc_t r_a = make_rsrc(p.a, p.m * p.k * 2u);
-
-  f4_t acc[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = f4_t{0.f, 0.f, 0.f, 0.f};
-  uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};
-  if constexpr (ABLATE & 8) stamp[0] = __builtin_amdgcn_s_memrealtime();
-
-  for (uint32_t b0 = 0; b0 < p.batches; b0 += T) {
-    const uint32_t wb = b0 + wv * LK;  // first batch of this wave in this sweep
-    const uint32_t bt = wb + kl;       // this lane's batch
-    const bool active = GUARD ? (col_ok && bt < p.batches) : true;
-
-    // (1) activation slice of this wave (oldest loads in the vmcnt queue).  Rows >= M fall off the
-    //     end of the buffer and read 0; k >= K must be forced out of range (it would alias row m+1).
-    u32x4_t hraw[ROUNDS][CPT];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int s = (lane + 64 * r) % NTASK;
-      const int mi = s / (LK * UB * (32 / CHK)), ch = s % (LK * UB * (32 / CHK));
-      const uint32_t k0 = wb * (uint32_t)(UB * 32) + (uint32_t)(ch * CHK);
-      uint32_t aoff = ((m0 + mi) * p.k + k0) * 2u;
-      if (GUARD && (k0 >= p.k || m0 + mi >= p.m)) aoff = kOob;  // k % 8 == 0: chunks are all-in or all-out
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        uint32_t o = aoff + 16u * q;
-        if (GUARD && CPT > 1 && k0 + 8u * q >= p.k) o = kOob;
-        hraw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
-      }
-    }
-
-    // (2) scale and zero-point of the batch's group (one group per batch on this path); a group
-    //     index past the end reads scale 0, which makes every weight of that lane exactly 0
-    const uint32_t gi = (bt * (uint32_t)(UB * 32)) / p.groupsize;
-    uint32_t sbits[CPL];
-    {
-      // CPL fp16 scales starting at half index h0: one 4- or 8-byte load from the enclosing dword(s)
-      const uint32_t h0 = gi * p.n + col;
-      uint32_t soff = (h0 & ~1u) * 2u;
-      if (GUARD && !active) soff = kOob;
-      if constexpr (CPL == 2) {  // col and n are even: h0 is even
-        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r_s, soff, 0, 0);
-        sbits[0] = v & 0xFFFFu;
-        sbits[1] = v >> 16;
-      } else {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_s, soff, 0, 0);
-        const uint32_t sh = (h0 & 1u) * 16u;  // CPL == 4: col % 4 == 0 and n even, so h0 is even and sh == 0
-        const uint32_t lo = __builtin_amdgcn_alignbit(v.y, v.x, sh), hi = v.y >> sh;
-        sbits[0] = lo & 0xFFFFu;
-        sbits[1] = lo >> 16;
-        sbits[2] = hi & 0xFFFFu;
-        if constexpr (CPL == 4) sbits[3] = hi >> 16;
-      }
-    }
-    uint32_t zwin;
-    {
-      const uint32_t bit = col * BITS, sh = bit & 31u;
-      const uint32_t zoff = (gi * p.zw + (bit >> 5)) * 4u;
-      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
-        zwin = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0) >> sh;  // the CPL fields never straddle a word
-      } else {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_z, zoff, 0, 0);  // a read past the row end is harmless
-        zwin = __builtin_amdgcn_alignbit(v.y, v.x, sh);
-      }
-    }
-
-    // (3) all packed-weight loads of this lane's batch: one 32-bit lane offset, the row step rides in
-    //     the scalar offset.  Rows past the end of qweight read 0 (their activations are 0 as well).
-    RowLoad<CPL, NT> w[UB][BITS];
-    uint32_t lane_off = (bt * (uint32_t)(UB * BITS)) * row_bytes + col * 4u;
-    if (GUARD && !active) lane_off = kOob;
-    using LS = LoadSchedule<BITS, UB, LA>;
-    auto issue_range = [&](auto from_c, auto to_c) {
-      constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
-      static_for<(to > from ? to - from : 0)>([&](auto d) {
-        constexpr int idx = from + decltype(d)::value, j = idx / BITS, i = idx % BITS;
-        if constexpr (ABLATE & 1) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) w[j][i].v[c] = lane_off * (uint32_t)(2 * c + 3) + (uint32_t)idx * 0x9E3779B1u;
-        } else {
-          w[j][i].load(r_w, lane_off, (uint32_t)idx * row_bytes);
-        }
-      });
-    };
-    issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, LS::issued_before(0)>{});
-    // Pin the issue order act -> scale/zero -> weights: each wait below then leaves every younger
-    // load in flight (vmcnt retires in order).
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (ABLATE & 8) {
-      if (b0 == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();  // all loads of the first sweep issued
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // (4) permute each chunk into pair order and park it in this wave's LDS region (every lane
-    //     stores; lanes beyond NTASK repeat a task with identical data)
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int s = (lane + 64 * r) % NTASK;
-      const int mi = s / (LK * UB * (32 / CHK)), ch = s % (LK * UB * (32 / CHK));
-      const int blk = ch / (32 / CHK), cib = ch % (32 / CHK);  // k-block of the slice, chunk inside it
-      uint32_t h[CHK / 2];
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        h[4 * q + 0] = hraw[r][q].x;
-        h[4 * q + 1] = hraw[r][q].y;
-        h[4 * q + 2] = hraw[r][q].z;
-        h[4 * q + 3] = hraw[r][q].w;
-      }
-      uint32_t* dst = my_act + (mi * LK + blk / UB) * KLS + (blk % UB) * 16 + cib * (CHK / 2);
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        uint32_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // pair (4q+e) of this chunk; pair_k is periodic in the chunk, so chunk 0's table serves all
-          const int pr = 4 * q + e;
-          const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
-          static_assert(Unpack<BITS>::pair_k(CHK / 2 - 1, 1) < CHK, "pairs stay inside a chunk");
-          const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) |
-                               ((uint32_t)(4 + 2 * (khi & 1)) << 16) | ((uint32_t)(5 + 2 * (khi & 1)) << 24);
-          o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
-        }
-        *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
-      }
-    }
-    // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if constexpr (ABLATE & 8) {
-      if (b0 == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();  // activations staged
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // (5) per-column dequant constants
-    half2_t s2[CPL], nzs2[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const _Float16 s = as_h((uint16_t)sbits[c]);
-      const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + p.bias;
-      s2[c] = splat(s);
-      nzs2[c] = splat(neg_zero_times_scale(z, s));
-    }
-
-    // (6) unpack + dequantise on the VALU, multiply-accumulate on the matrix pipe; the loads of
-    //     the steps LA ahead are issued in front of each step
-    static_for<UB * 4>([&](auto step_c) {
-      constexpr int step = decltype(step_c)::value, j = step / 4, oct = step % 4;
-      if constexpr (LA > 0 && step > 0) {
-        issue_range(std::integral_constant<int, LS::issued_before(step - 1)>{}, std::integral_constant<int, LS::issued_before(step)>{});
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      uint32_t wc[CPL][BITS];
-#pragma unroll
-      for (int c = 0; c < CPL; ++c)
-#pragma unroll
-        for (int i = 0; i < BITS; ++i) wc[c][i] = w[j][i].v[c];
-
-      if constexpr (ABLATE & 2) {
-        if constexpr (oct == 0) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c)
-#pragma unroll
-            for (int i = 0; i < BITS; ++i) acc[c][0] += __builtin_bit_cast(float, wc[c][i] & 0x3FFFFFFFu);
-        }
-      } else {
-        const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + (arow * LK + kl) * KLS + j * 16 + 4 * oct);
-        const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
-        u32x4_t braw[CPL];
-        static_for<4>([&](auto e_c) {
-          constexpr int e = decltype(e_c)::value;
-          constexpr int pr = 4 * oct + e;
-          uint32_t Q[CPL];
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template pair<pr>(wc[c], uk);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]));
-        });
-#pragma unroll
-        for (int c = 0; c < CPL; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
-      }
-      if constexpr (LA > 0) __builtin_amdgcn_sched_barrier(0);
-    });
-    __builtin_amdgcn_wave_barrier();  // keep the next sweep's LDS writes behind these reads
-  }
-  if constexpr (ABLATE & 8) {
-    asm volatile("" : "+v"(acc[0]));
-    __builtin_amdgcn_sched_barrier(0);
-    stamp[3] = __builtin_amdgcn_s_memrealtime();  // last MFMA issued (its operands were ready)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // D[drow][slot]: drow = 4*(lane>>4) + r lives in register r of lane (lane>>4, slot = lane&15).
-  // Keep the quadrant where the row block equals the slot's k-slot, then sum over k-slots and waves.
-  {
-    const int slot = lane & 15, ks = slot / NL, snl = slot % NL;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int drow = 4 * (lane >> 4) + r;
-        const int m = drow % RB;
-        if (drow / RB == ks && m < MT) s_red[((wv * RS + ks) * MT + m) * CN + snl * CPL + c] = acc[c][r];
-      }
-  }
-  __syncthreads();
-  if constexpr (ABLATE & 8) stamp[4] = __builtin_amdgcn_s_memrealtime();  // past the workgroup barrier
-  for (int e = tid; e < MT * CN; e += 64 * NW) {
-    const int m = e / CN, c = e % CN;
-    float sum = 0.f;
-#pragma unroll
-    for (int v = 0; v < NW * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
-    const uint32_t n_out = tile * CN + c, row = m0 + m;
-    if (!GUARD || (n_out < p.n && row < p.m)) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
-  }
-  if constexpr (ABLATE & 8) {
-    stamp[5] = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0 && p.trace != nullptr) {
-      uint64_t* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wv) * 8;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) o[i] = stamp[i];
-    }
-  }
-}
-
-constexpr int kLookahead = 4;  // row loads in flight ahead of the MFMA step being computed (see LA)
-
-template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, int LA = kLookahead>
-int launch_one(GemvParams p, hipStream_t stream) {
-  constexpr int CN = NL * CPL, T = (64 / NL) * NW;
-  p.tiles = (p.n + CN - 1) / CN;
-  const uint32_t kblocks = (p.k + 31) / 32;
-  p.batches = (kblocks + UB - 1) / UB;
-  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * NW);
-  const bool exact = (p.k % (32u * UB) == 0) && (p.batches % T == 0) && (p.n % CN == 0) && (p.m % MT == 0);
-  if (exact) return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, NT, false, 0, LA>, grid, block, stream, p);
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, NT, true, 0, LA>, grid, block, stream, p);
-}
-
-// measurement-only launches (M = 1, plain loads): ablated or stamped builds, see ABLATE
-template <int BITS, int UB, int CPL, int NL, int NW, int ABLATE, int LA>
-int launch_la(GemvParams p, hipStream_t stream) {
-  constexpr int CN = NL * CPL;
-  p.tiles = (p.n + CN - 1) / CN;
-  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  dim3 grid(p.tiles, p.m), block(64 * NW);
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
-}
-
-// rows per pass: 1, 4, 8 or 16 (fewer staged rows = less LDS traffic); NL = 8 tiles take <= 8 rows
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int LA = kLookahead>
-int launch_rows(const GemvParams& p, hipStream_t stream) {
-  if (p.m == 1) return launch_one<BITS, UB, CPL, NL, NW, 1, NT, LA>(p, stream);
-  if (p.m <= 4) return launch_one<BITS, UB, CPL, NL, NW, 4, NT, LA>(p, stream);
-  // 8-16 rows: the staged activation tile is much larger, so fewer waves and smaller batches
-  constexpr int UBR = UB > 2 ? 2 : UB;
-  if (p.m <= 8) return launch_one<BITS, UBR, CPL, NL, 4, 8, NT>(p, stream);
-  return launch_one<BITS, UBR, CPL, 16, 4, 16, NT>(p, stream);
-}
-
-template <int BITS>
-constexpr int max_ub() {
-  return BITS <= 4 ? 4 : 2;  // <= 16 outstanding row loads per lane
-}
-
-// Tiles are 16*CPL columns wide.  Prefer the width whose tile count wastes the fewest CU slots
-// (tiles / (ceil(tiles/256)*256)); ties go to the wider load (longer contiguous row segments).
-inline int pick_cpl(uint32_t n) {
-  int best = 2;
-  double best_eff = -1.0;
-  for (int cpl = 2; cpl <= 4; ++cpl) {
-    const uint32_t tiles = (n + 16u * cpl - 1) / (16u * cpl);
-    const double eff = (double)n / (16.0 * cpl) / (double)(((tiles + 255u) / 256u) * 256u);
-    if (eff >= best_eff - 1e-9) {
-      best_eff = eff;
-      best = cpl;
-    }
-  }
-  return best;
-}
-
-template <int BITS, int UB, int NW>
-int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl) {
-  switch (cpl) {
-    // plain (not nontemporal) loads: equal to nt when the weights come from HBM, ~8 % faster when
-    // they are still in the Infinity Cache (measured: profiles/r01/sweep_*.txt)
-    case 4: return launch_rows<BITS, UB, 4, 16, NW, false>(p, stream);
-    case 3: return launch_rows<BITS, UB, 3, 16, NW, false>(p, stream);
-    default: return launch_rows<BITS, UB, 2, 16, NW, false>(p, stream);
-  }
-}
-
-template <int BITS>
-int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
-  constexpr int UBMAX = max_ub<BITS>();
-  const uint32_t kblocks = (p.k + 31) / 32;
-  const int cpl = pick_cpl(p.n);
-  if (p.groupsize % (32u * UBMAX) == 0) {
-    if constexpr (BITS == 4) {  // tuning variants exist for the headline bit-width only
-      switch (variant) {
-        case 11: return launch_rows<BITS, 4, 2, 16, 8, true>(p, stream);
-        case 12: return launch_rows<BITS, 4, 3, 16, 8, true>(p, stream);
-        case 21: return launch_rows<BITS, 4, 2, 16, 8, false>(p, stream);
-        case 22: return launch_rows<BITS, 4, 4, 16, 8, false>(p, stream);
-        case 13: return launch_rows<BITS, 4, 4, 16, 8, true>(p, stream);
-        case 14: return launch_rows<BITS, 2, 3, 16, 16, true>(p, stream);
-        case 15: return launch_rows<BITS, 4, 3, 16, 8, false>(p, stream);
-        case 16: return launch_rows<BITS, 4, 3, 16, 8, true, 0>(p, stream);
-        case 17: return launch_rows<BITS, 4, 3, 16, 8, true, 2>(p, stream);
-        case 18: return launch_rows<BITS, 4, 3, 16, 8, true, 6>(p, stream);
-        case 19: return launch_rows<BITS, 4, 3, 16, 8, true, 8>(p, stream);
-        case 20: return launch_rows<BITS, 2, 3, 16, 16, true, 2>(p, stream);
-        case 31: return launch_la<BITS, 4, 3, 16, 8, 1, kLookahead>(p, stream);
-        case 32: return launch_la<BITS, 4, 3, 16, 8, 2, kLookahead>(p, stream);
-        case 33: return launch_la<BITS, 4, 3, 16, 8, 3, kLookahead>(p, stream);
-        case 61: return launch_la<BITS, 2, 3, 16, 16, 8, kLookahead>(p, stream);
-        case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);
-        default: break;
-      }
-    }
-    // enough waves to cover K in one sweep when possible (T = 4*NW batches per sweep)
-    if (kblocks / UBMAX >= 64) return launch_cpl<BITS, UBMAX, 16>(p, stream, cpl);
-    return launch_cpl<BITS, UBMAX, 8>(p, stream, cpl);
-  }
-  if constexpr (UBMAX > 2) {
-    if (p.groupsize % 64u == 0) return launch_cpl<BITS, 2, 8>(p, stream, cpl);
-  }
-  return launch_cpl<BITS, 1, 8>(p, stream, cpl);
-}
-
-}  // namespace
+int launch_gemv_mfma_b2(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b3(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b4(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b5(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b6(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b7(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b8(const GemvParams& p, hipStream_t stream, int variant);
 
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int variant) {
   switch (bits) {
-    case 2: return launch_bits<2>(p, stream, variant);
-    case 3: return launch_bits<3>(p, stream, variant);
-    case 4: return launch_bits<4>(p, stream, variant);
-    case 5: return launch_bits<5>(p, stream, variant);
-    case 6: return launch_bits<6>(p, stream, variant);
-    case 7: return launch_bits<7>(p, stream, variant);
-    case 8: return launch_bits<8>(p, stream, variant);
+    case 2: return launch_gemv_mfma_b2(p, stream, variant);
+    case 3: return launch_gemv_mfma_b3(p, stream, variant);
+    case 4: return launch_gemv_mfma_b4(p, stream, variant);
+    case 5: return launch_gemv_mfma_b5(p, stream, variant);
+    case 6: return launch_gemv_mfma_b6(p, stream, variant);
+    case 7: return launch_gemv_mfma_b7(p, stream, variant);
+    case 8: return launch_gemv_mfma_b8(p, stream, variant);
     default: return XBIT_ERR_BITS;
   }
 }

@@ -1,0 +1,8 @@
+// xbit_gemv_mfma_b2.hip — 2-bit instantiation of the MFMA GEMV (see xbit_gemv_mfma.h).
+#include "xbit_gemv_mfma.h"
+
+namespace xbit {
+
+int launch_gemv_mfma_b2(const GemvParams& p, hipStream_t stream, int variant) { return launch_bits<2>(p, stream, variant); }
+
+}  // namespace xbit

@@ -1,0 +1,8 @@
+// xbit_gemv_mfma_b4.hip — 4-bit instantiation of the MFMA GEMV (see xbit_gemv_mfma.h).
+#include "xbit_gemv_mfma.h"
+
+namespace xbit {
+
+int launch_gemv_mfma_b4(const GemvParams& p, hipStream_t stream, int variant) { return launch_bits<4>(p, stream, variant); }
+
+}  // namespace xbit

@@ -1,0 +1,8 @@
+// xbit_gemv_mfma_b7.hip — 7-bit instantiation of the MFMA GEMV (see xbit_gemv_mfma.h).
+#include "xbit_gemv_mfma.h"
+
+namespace xbit {
+
+int launch_gemv_mfma_b7(const GemvParams& p, hipStream_t stream, int variant) { return launch_bits<7>(p, stream, variant); }
+
+}  // namespace xbit
