@@ -84,16 +84,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--shape", default="4096,11008,4,128,1", help="K,N,bits,group,M for the variant loop")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
     print("device:", torch.cuda.get_device_name(0), flush=True)
+    sk, sn, sb, sg, sm = (int(x) for x in args.shape.split(","))
     for v in [int(x) for x in args.variants.split(",") if x != ""]:
         raw.xbit_debug_set_gemv_variant(v)
-        show("gemv w4 4096x11008 m1 variant %d cold" % v, *gemv_case(lib, dev, 4096, 11008, 4, 128, 1, True))
-        show("gemv w4 4096x11008 m1 variant %d warm" % v, *gemv_case(lib, dev, 4096, 11008, 4, 128, 1, False))
+        show("gemv w%d %dx%d m%d variant %d cold" % (sb, sk, sn, sm, v), *gemv_case(lib, dev, sk, sn, sb, sg, sm, True, 100 if sk * sn > 1e8 else 200))
+        show("gemv w%d %dx%d m%d variant %d warm" % (sb, sk, sn, sm, v), *gemv_case(lib, dev, sk, sn, sb, sg, sm, False, 100 if sk * sn > 1e8 else 200))
     raw.xbit_debug_set_gemv_variant(-1)
     if args.quick:
         return

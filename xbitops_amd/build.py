@@ -68,6 +68,10 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # a kernel whose host stub was dropped shows up as an undefined symbol only at load time
+    chk = subprocess.run([sys.executable, "-c", "import ctypes,sys; ctypes.CDLL(sys.argv[1])", LIB + ".tmp"], capture_output=True, text=True)
+    if chk.returncode != 0:
+        raise RuntimeError("built library does not load:\n" + chk.stderr)
     os.replace(LIB + ".tmp", LIB)
     if verbose:
         print("built", LIB)

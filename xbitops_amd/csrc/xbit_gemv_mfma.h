@@ -441,6 +441,11 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
         case 12: return launch_rows<BITS, 4, 3, 16, 8, true>(p, stream);
         case 21: return launch_rows<BITS, 4, 2, 16, 8, false>(p, stream);
         case 22: return launch_rows<BITS, 4, 4, 16, 8, false>(p, stream);
+        case 23: return launch_rows<BITS, 4, 2, 16, 16, false>(p, stream);
+        case 24: return launch_rows<BITS, 4, 3, 16, 16, false>(p, stream);
+        case 25: return launch_rows<BITS, 4, 4, 16, 16, false>(p, stream);
+        case 26: return launch_rows<BITS, 4, 4, 16, 4, false>(p, stream);
+        case 27: return launch_rows<BITS, 4, 2, 16, 4, false>(p, stream);
         case 13: return launch_rows<BITS, 4, 4, 16, 8, true>(p, stream);
         case 14: return launch_rows<BITS, 2, 3, 16, 16, true>(p, stream);
         case 15: return launch_rows<BITS, 4, 3, 16, 8, false>(p, stream);
