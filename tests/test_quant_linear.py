@@ -1,0 +1,41 @@
+"""QuantLinear: the packer's quantise->pack round trip (CPU) and the module on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from xbitops_amd import packing
+
+
+@pytest.mark.parametrize("bits,bias", [(2, 0), (3, 1), (4, 1), (8, 0)])
+def test_quantize_pack_round_trip(bits, bias):
+    rng = np.random.default_rng(bits)
+    w = rng.normal(0, 0.05, size=(256, 64)).astype(np.float32)
+    qweight, scales, qzeros = packing.quantize_rtn(w, bits, 64, add_zero_bias=bias)
+    q = oracle.unpack_q(qweight, bits, 256).astype(np.float32)
+    z = oracle.unpack_z(qzeros, bits, 64).astype(np.float32) + bias
+    gi = np.arange(256) // 64
+    recon = (q - z[gi]) * scales.astype(np.float32)[gi]
+    step = scales.astype(np.float32)[gi]
+    # within half a quantisation step, plus the fp16 rounding of the scale seen through up to maxq steps
+    assert (np.abs(recon - w) <= (0.5 + ((1 << bits) - 1) * 2.0 ** -10) * step + 1e-6).all()
+    w_deq = oracle.dequant(qweight, scales, qzeros, 64, bits, 256, bias).astype(np.float32)
+    assert np.abs(w_deq - recon).max() <= 2e-3 * np.abs(recon).max() + 1e-4  # fp16 rounding of the same value
+
+
+@pytest.mark.gpu
+def test_quant_linear_forward(cuda_device):
+    from xbitops_amd.linear import QuantLinear
+
+    torch.manual_seed(0)
+    w = torch.randn(512, 128) * 0.05
+    layer = QuantLinear.from_float(w, bits=4, groupsize=128, add_zero_bias=1).to(cuda_device)
+    w_deq = layer.dequantize().float()
+    assert (w_deq.cpu() - w).abs().max() < 0.05
+    for rows in (1, 5, 40):  # GEMV path, skinny path, dequant + GEMM path
+        x = (torch.randn(rows, 512, device=cuda_device) * 0.5).half()
+        y = layer(x)
+        y_ref = x.float() @ w_deq
+        assert y.shape == (rows, 128)
+        assert (y.float() - y_ref).abs().max() <= 2e-3 * y_ref.abs().max() + 1e-3
+    assert layer(torch.zeros(2, 3, 512, device=cuda_device).half()).shape == (2, 3, 128)
