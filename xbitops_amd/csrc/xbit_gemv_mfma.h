@@ -391,10 +391,11 @@ template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int LA = kLookahea
 int launch_rows(const GemvParams& p, hipStream_t stream) {
   if (p.m == 1) return launch_one<BITS, UB, CPL, NL, NW, 1, NT, LA>(p, stream);
   if (p.m <= 4) return launch_one<BITS, UB, CPL, NL, NW, 4, NT, LA>(p, stream);
-  // 8-16 rows: the staged activation tile is much larger, so fewer waves and smaller batches
-  constexpr int UBR = UB > 2 ? 2 : UB;
-  if (p.m <= 8) return launch_one<BITS, UBR, CPL, NL, 4, 8, NT>(p, stream);
-  return launch_one<BITS, UBR, CPL, 16, 4, 16, NT>(p, stream);
+  // 8-16 rows: the staged activation tile is 8-16x larger (LDS: NW*MT*4*(UB*16+4)*4 bytes, 139 KB
+  // at UB = 4, NW = 8, MT = 16).  Measured on 4096x11008 w4 M=16: NW = 8 is 9.0-9.3 us, NW = 4 11.0 us.
+  if (p.m <= 8) return launch_one<BITS, UB, CPL, NL, 8, 8, NT, LA>(p, stream);
+  constexpr int UB16 = UB > 2 ? 2 : UB;  // keeps activations + reduction scratch under the 160 KB of LDS at every CPL
+  return launch_one<BITS, UB16, CPL, 16, 8, 16, NT, LA>(p, stream);
 }
 
 template <int BITS>
@@ -441,6 +442,12 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
         case 12: return launch_rows<BITS, 4, 3, 16, 8, true>(p, stream);
         case 21: return launch_rows<BITS, 4, 2, 16, 8, false>(p, stream);
         case 22: return launch_rows<BITS, 4, 4, 16, 8, false>(p, stream);
+        case 91: return launch_one<BITS, 2, 3, 16, 4, 16, false>(p, stream);
+        case 92: return launch_one<BITS, 2, 3, 16, 8, 16, false>(p, stream);
+        case 93: return launch_one<BITS, 4, 3, 16, 8, 16, false>(p, stream);
+        case 94: return launch_one<BITS, 1, 3, 16, 8, 16, false>(p, stream);
+        case 95: return launch_one<BITS, 1, 3, 16, 16, 16, false>(p, stream);
+        case 96: return launch_one<BITS, 2, 4, 16, 8, 16, false>(p, stream);
         case 23: return launch_rows<BITS, 4, 2, 16, 16, false>(p, stream);
         case 24: return launch_rows<BITS, 4, 3, 16, 16, false>(p, stream);
         case 25: return launch_rows<BITS, 4, 4, 16, 16, false>(p, stream);
