@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--gather-bucket", type=int, default=8, help="N>1: steps per all-gather bucket")
+    ap.add_argument("--gather-bucket", type=int, default=32, help="N>1: steps per all-gather bucket")
     ap.add_argument("--variant", type=int, default=-1, help="tuning: GEMV launch-shape variant")
     return ap.parse_args()
 
