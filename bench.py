@@ -167,6 +167,8 @@ def main():
     comm = torch.cuda.Stream(dev) if world > 1 else None
     bucket = max(1, args.gather_bucket)
 
+    gathered_ev = [None, None]  # per output half: the all-gather that last read it
+
     def gather_bucket(b: int) -> None:
         """all-gather the `bucket` outputs of bucket b on the side stream (after they are computed)."""
         half = b % 2
@@ -176,10 +178,14 @@ def main():
         with torch.cuda.stream(comm):
             comm.wait_event(ev)
             dist.all_gather_into_tensor(gathered[half].view(-1), src.reshape(-1))
+            gathered_ev[half] = torch.cuda.Event()
+            gathered_ev[half].record(comm)
 
     def run_steps(first: int, count: int) -> None:
         sp = torch.cuda.current_stream(dev).cuda_stream
         for i in range(first, first + count):
+            if world > 1 and i % bucket == 0 and gathered_ev[(i // bucket) % 2] is not None:
+                compute.wait_event(gathered_ev[(i // bucket) % 2])  # do not overwrite outputs still being gathered
             step(i, sp)
             if world > 1 and (i + 1) % bucket == 0:
                 gather_bucket(i // bucket)
