@@ -167,7 +167,10 @@ def test_gemv_w4_llama70b_ffn_shard_and_full(cuda_device):
     for r in (0, 5, 7):
         qw_r, sc_r, qz_r = sharded.shard_columns(qw, sc, qz, 4, 8, r)
         y_r = XbitOps.gemv(a, qw_r, sc_r, qz_r, 128, 4, 8192, 1)
-        assert torch.equal(y_r, y_full[:, r * 3584:(r + 1) * 3584])
+        # the shard may run a different tile shape than the full layer (different fp32 summation
+        # order), so the two agree to the last fp16 bit, not bit for bit
+        d = (y_r.view(torch.int16).int() - y_full[:, r * 3584:(r + 1) * 3584].contiguous().view(torch.int16).int()).abs()
+        assert int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.98
     qw_r, sc_r, qz_r = sharded.shard_columns(p.qweight, p.scales, p.qzeros, 4, 8, 5)
     y_ref = oracle.gemv(p.act, qw_r, sc_r, qz_r, 128, 4, 8192, 1, oracle.RNE)
     assert_gemv_close(y_full[:, 5 * 3584:6 * 3584].cpu().numpy(), y_ref, "cfg4 shard 5")
