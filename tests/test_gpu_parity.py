@@ -169,8 +169,10 @@ def test_gemv_w4_llama70b_ffn_shard_and_full(cuda_device):
         y_r = XbitOps.gemv(a, qw_r, sc_r, qz_r, 128, 4, 8192, 1)
         # the shard may run a different tile shape than the full layer (different fp32 summation
         # order), so the two agree to the last fp16 bit, not bit for bit
-        d = (y_r.view(torch.int16).int() - y_full[:, r * 3584:(r + 1) * 3584].contiguous().view(torch.int16).int()).abs()
-        assert int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.98
+        y_f = y_full[:, r * 3584:(r + 1) * 3584].contiguous()
+        d = (y_r.view(torch.int16).int() - y_f.view(torch.int16).int()).abs()
+        near_zero = (y_r.float() - y_f.float()).abs() <= 3e-5  # fp32 summation noise over K = 8192 where the sum cancels
+        assert bool(((d <= 1) | near_zero).all()) and float((d == 0).float().mean()) > 0.98
     qw_r, sc_r, qz_r = sharded.shard_columns(p.qweight, p.scales, p.qzeros, 4, 8, 5)
     y_ref = oracle.gemv(p.act, qw_r, sc_r, qz_r, 128, 4, 8192, 1, oracle.RNE)
     assert_gemv_close(y_full[:, 5 * 3584:6 * 3584].cpu().numpy(), y_ref, "cfg4 shard 5")
@@ -272,3 +274,33 @@ def test_sharded_wrapper_single_rank_uses_hip_op(cuda_device):
 
     y1 = XbitOps.gemv(a, qw0, sc0, qz0, 128, 4, 2048, 1)
     assert torch.equal(y1, y[:, 64:128])
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 6, 8])
+def test_adversarial_scales_and_zero_points(bits, cuda_device):
+    """Negative, zero, subnormal and large scales; extreme zero-points and bias: the rebuilt W must
+    still be the IEEE result bit for bit (subnormal results included), and the GEMV must follow."""
+    k, n, g = 512, 96, 64
+    p = synth.make_problem(k, n, bits, g, m=2, seed=500 + bits)
+    rng = np.random.default_rng(bits)
+    sc = p.scales.astype(np.float32)
+    kinds = rng.integers(0, 6, size=sc.shape)
+    sc = np.where(kinds == 0, -sc, sc)                      # negative
+    sc = np.where(kinds == 1, 0.0, sc)                      # zero
+    sc = np.where(kinds == 2, sc * 2.0 ** -12, sc)          # results in the fp16 subnormal range
+    sc = np.where(kinds == 3, sc * 64.0, sc)                # large
+    sc = np.where(kinds == 4, np.float32(6.0e-8), sc)       # smallest subnormal scale
+    p.scales = sc.astype(np.float16)
+    z = rng.integers(0, 1 << bits, size=(p.groups, n), dtype=np.uint8)
+    z[:, ::3] = (1 << bits) - 1
+    z[:, 1::5] = 0
+    p.qzeros = packing.pack_qzeros(z, bits)
+    for bias in (0, 1, 255):
+        w = run_dequant(p, bias, cuda_device)
+        w_ref = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, bias, oracle.RNE)
+        assert np.array_equal(_bits(w), _bits(w_ref)), (bits, bias)
+    y = run_gemv(p, 1, cuda_device)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+    ok = np.isfinite(y_ref.astype(np.float32))
+    err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+    assert (err[ok] <= 1e-3 * np.abs(y_ref.astype(np.float64))[ok] + 2.0 ** -14).all()
