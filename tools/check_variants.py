@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Correctness of tuning variants against the default GEMV path (GPU): python tools/check_variants.py 81,82"""
+"""Correctness of tuning variants against the default GEMV path (GPU): python tools/check_variants.py 12,13,21"""
 import ctypes
 import os
 import sys
@@ -12,7 +12,7 @@ from xbitops_amd import _lib, synth  # noqa: E402
 
 
 def main():
-    variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "81").split(",")]
+    variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "12,13,15,21,22").split(",")]
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     raw = ctypes.CDLL(_lib.LIB_PATH)
