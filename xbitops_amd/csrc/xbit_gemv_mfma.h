@@ -362,7 +362,13 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   }
 }
 
-constexpr int kLookahead = 4;  // row loads in flight ahead of the MFMA step being computed (see LA)
+// row loads in flight ahead of the MFMA step being computed (see LA); measured per width on
+// 4096x11008 (profiles/r01/sweep_lookahead_by_width.txt): 4 for 2/3/4/8 bit, 6 for 6 bit
+constexpr int kLookahead = 4;
+template <int BITS>
+constexpr int lookahead_for() {
+  return (BITS >= 5 && BITS <= 7) ? 6 : kLookahead;
+}
 
 template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, int LA = kLookahead>
 int launch_one(GemvParams p, hipStream_t stream) {
@@ -387,7 +393,7 @@ int launch_la(GemvParams p, hipStream_t stream) {
 }
 
 // rows per pass: 1, 4, 8 or 16 (fewer staged rows = less LDS traffic); NL = 8 tiles take <= 8 rows
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int LA = kLookahead>
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int LA = lookahead_for<BITS>()>
 int launch_rows(const GemvParams& p, hipStream_t stream) {
   if (p.m == 1) return launch_one<BITS, UB, CPL, NL, NW, 1, NT, LA>(p, stream);
   if (p.m <= 4) return launch_one<BITS, UB, CPL, NL, NW, 4, NT, LA>(p, stream);
@@ -436,6 +442,13 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
   const uint32_t kblocks = (p.k + 31) / 32;
   const int cpl = pick_cpl(p.n);
   if (p.groupsize % (32u * UBMAX) == 0) {
+    switch (variant) {  // lookahead sweep, every bit-width (48-column tiles)
+      case 101: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 2>(p, stream);
+      case 102: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 6>(p, stream);
+      case 103: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 8>(p, stream);
+      case 104: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 4>(p, stream);
+      default: break;
+    }
     if constexpr (BITS == 4) {  // tuning variants exist for the headline bit-width only
       switch (variant) {
         case 11: return launch_rows<BITS, 4, 2, 16, 8, true>(p, stream);
