@@ -304,3 +304,72 @@ def test_adversarial_scales_and_zero_points(bits, cuda_device):
     ok = np.isfinite(y_ref.astype(np.float32))
     err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
     assert (err[ok] <= 1e-3 * np.abs(y_ref.astype(np.float64))[ok] + 2.0 ** -14).all()
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_gemv_rebuilds_w_bit_exact_one_hot(bits, cuda_device):
+    """One-hot activations make y[m, :] = W[k_m, :] exactly (1.0 * W summed with zeros, one final
+    rounding of an fp16 value), so the GEMV's in-register dequantisation — the subnormal-form fast
+    path and, for the scales too large for it, the spliced form — is compared BIT FOR BIT with the
+    oracle's W for every bit-width, at M = 1, 4, 16 (every rows-per-pass build)."""
+    k, n, g = 1024, 176, 128
+    p = synth.make_problem(k, n, bits, g, m=16, seed=900 + bits)
+    rng = np.random.default_rng(40 + bits)
+    sc = p.scales.astype(np.float32)
+    kinds = rng.integers(0, 8, size=sc.shape)
+    sc = np.where(kinds == 0, -sc, sc)
+    sc = np.where(kinds == 1, sc * 2.0 ** -10, sc)          # W in the fp16 subnormal range
+    sc = np.where(kinds == 2, np.float32(6.0e-8), sc)       # smallest subnormal scale
+    sc = np.where(kinds == 3, sc * 256.0, sc)               # beyond the fast path's scale range
+    sc[:, 64:112] = np.abs(sc[:, 64:112]) * 0.5             # whole tiles inside the fast path's range
+    p.scales = sc.astype(np.float16)
+    w_ref = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+    rows = rng.choice(k, size=16, replace=False)
+    act = np.zeros((16, k), np.float16)
+    act[np.arange(16), rows] = 1.0
+    import XbitOps
+
+    _a, qw, scd, qz = to_dev(p, cuda_device)
+    for m in (1, 4, 16):
+        a = torch.from_numpy(act[:m]).to(cuda_device)
+        y = XbitOps.gemv(a, qw, scd, qz, g, bits, k, 1).cpu().numpy()
+        want = w_ref[rows[:m]]
+        # -0.0 + 0.0 accumulates to +0.0: compare values, and bits wherever W is not a zero
+        nz = want != 0
+        assert np.array_equal(_bits(y)[nz], _bits(want)[nz]), (bits, m)
+        assert (y[~nz] == 0).all(), (bits, m)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 8])
+def test_gemv_split_k_shapes(bits, cuda_device):
+    """Small N and long K: the launcher splits K over workgroups (partial sums in the per-stream
+    workspace, the last arriver adds them in split order).  Repeated launches reuse the tickets; a
+    second stream gets its own workspace; ragged K / N and M = 3, 4 go through the same path.  The
+    last case forces a split factor on a shape the heuristic would not split."""
+    import ctypes
+
+    import XbitOps
+    from xbitops_amd import _lib
+
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
+    try:
+        for k, n, m, forced in ((16384, 256, 1, 0), (14336 + 512, 130, 3, 0), (14336, 512, 4, 0), (4096 + 512, 130, 3, 3), (8192, 1024, 1, 5)):
+            raw.xbit_debug_set_gemv_split(forced)
+            p = synth.make_problem(k, n, bits, 128, m=m, seed=bits * 41 + n + m)
+            y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, k, 1, oracle.RNE)
+            a, qw, sc, qz = to_dev(p, cuda_device)
+            ys = [XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1) for _ in range(3)]
+            side = torch.cuda.Stream(device=cuda_device)
+            side.wait_stream(torch.cuda.current_stream(cuda_device))
+            with torch.cuda.stream(side):
+                ys.append(XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1))
+            torch.cuda.synchronize()
+            for y in ys:
+                assert_gemv_close(y.cpu().numpy(), y_ref, "bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
+                assert torch.equal(y, ys[0])  # fixed summation order: launches agree bit for bit
+            raw.xbit_debug_set_gemv_split(1)  # never split: same result up to the summation order
+            y1 = XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1)
+            assert_gemv_close(y1.cpu().numpy(), y_ref, "unsplit bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
+    finally:
+        raw.xbit_debug_set_gemv_split(0)

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--shape", default="4096,11008,4,128,1", help="K,N,bits,group,M for the variant loop")
+    ap.add_argument("--splits", default="0", help="split-K factors to try per variant (0 = automatic, 1 = never split)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load()
@@ -92,11 +93,16 @@ def main():
     raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
     print("device:", torch.cuda.get_device_name(0), flush=True)
     sk, sn, sb, sg, sm = (int(x) for x in args.shape.split(","))
+    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
     for v in [int(x) for x in args.variants.split(",") if x != ""]:
-        raw.xbit_debug_set_gemv_variant(v)
-        show("gemv w%d %dx%d m%d variant %d cold" % (sb, sk, sn, sm, v), *gemv_case(lib, dev, sk, sn, sb, sg, sm, True, 100 if sk * sn > 1e8 else 200))
-        show("gemv w%d %dx%d m%d variant %d warm" % (sb, sk, sn, sm, v), *gemv_case(lib, dev, sk, sn, sb, sg, sm, False, 100 if sk * sn > 1e8 else 200))
+        for sp in [int(x) for x in args.splits.split(",")]:
+            raw.xbit_debug_set_gemv_variant(v)
+            raw.xbit_debug_set_gemv_split(sp)
+            tag = "variant %d" % v + (" split %d" % sp if sp else "")
+            show("gemv w%d %dx%d m%d %s cold" % (sb, sk, sn, sm, tag), *gemv_case(lib, dev, sk, sn, sb, sg, sm, True, 100 if sk * sn > 1e8 else 200))
+            show("gemv w%d %dx%d m%d %s warm" % (sb, sk, sn, sm, tag), *gemv_case(lib, dev, sk, sn, sb, sg, sm, False, 100 if sk * sn > 1e8 else 200))
     raw.xbit_debug_set_gemv_variant(-1)
+    raw.xbit_debug_set_gemv_split(0)
     if args.quick:
         return
     show("gemv w4 8192x28672 m1 cold (cfg4, 1 GPU)", *gemv_case(lib, dev, 8192, 28672, 4, 128, 1, True, 60))

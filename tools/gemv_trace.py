@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of the GEMV kernel (stamped measurement build, variants 41+): when did each
+"""Per-wave timeline of the GEMV kernel (stamped measurement build, variant 63): when did each
 wave start, finish issuing its loads, finish staging, issue its last MFMA, pass the barrier, end.
-    python tools/gemv_trace.py [--variants 41,42] [--warm]
+    python tools/gemv_trace.py [--shape K,N]
 """
 import argparse
 import ctypes
@@ -16,20 +16,22 @@ sys.path.insert(0, ROOT)
 from xbitops_amd import _lib, synth  # noqa: E402
 
 NAMES = ["wave start", "loads issued", "act staged", "last MFMA issued", "past barrier", "wave end"]
-NW = {41: 16, 42: 8, 43: 16, 44: 16, 61: 16, 63: 8}
-CN = {41: 48, 42: 48, 43: 64, 44: 48, 61: 48, 63: 48}
+NW = {63: 8}
+CN = {63: 48}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="61,63")
+    ap.add_argument("--variants", default="63")
+    ap.add_argument("--shape", default="4096,11008", help="K,N")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
     raw.xbit_debug_set_gemv_trace.argtypes = [ctypes.c_void_p]
-    k, n, bits, g, m = 4096, 11008, 4, 128, 1
+    k, n = [int(x) for x in args.shape.split(",")]
+    bits, g, m = 4, 128, 1
     nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
     copies = (512 << 20) // nbytes + 2
     base = synth.make_problem(k, n, bits, g, m=m, seed=1)

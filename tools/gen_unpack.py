@@ -109,6 +109,13 @@ def simulate(bits, pairs, trials=200):
             assert lo == 0x6400 + (field(klo) << pl["e"]), (bits, p)
             assert hi == 0x6400 + (field(klo + 8) << pl["e"]), (bits, p)
             assert pl["e"] + bits <= 10
+            # subnormal form: the same fields moved to mantissa bits [E, E + bits) with everything else cleared
+            E = 10 - bits
+            t = pl["shift"] + pl["e"] - E
+            assert -E <= t <= 6
+            y = ((x >> t) if t >= 0 else (x << -t)) & 0xFFFFFFFF
+            qs = y & ((((1 << bits) - 1) << E) * 0x00010001)
+            assert qs & 0xFFFF == field(klo) << E and qs >> 16 == field(klo + 8) << E, (bits, p)
 
 
 def main():
@@ -118,7 +125,9 @@ def main():
         "// Field-pair extraction for 3/5/6/7-bit k-blocks: pair p = (k, k+8) with k = 16*(p/8) + p%8.",
         "// Each expression is (X >> s) & (mask << e) | magic with X = one v_perm_b32 of two byte-aligned",
         "// 16-bit windows `bits` bytes apart (see the generator for the derivation); identical",
-        "// sub-expressions are merged by the compiler.  Verified against a bit-stream unpack at",
+        "// sub-expressions are merged by the compiler.  `sub_pair` is the same pair with the fields moved to",
+        "// a fixed mantissa position and nothing spliced in (fp16 subnormals q * 2^(10-BITS-24)): one full-rate",
+        "// shift + one v_and_b32 per pair on top of the shared perm.  Verified against a bit-stream unpack at",
         "// generation time.",
         "#pragma once",
         "",
@@ -151,6 +160,19 @@ def main():
             if pl["shift"]:
                 x = "(%s >> %d)" % (x, pl["shift"])
             lines.append("    %sif constexpr (P == %d) return (%s & k.mask[%d]) | k.magic;" % ("" if p == 0 else "else ", p, x, pl["e"]))
+        lines.append("    else return 0u;")
+        lines.append("  }")
+        lines.append("  // subnormal form: both fields at mantissa bits [10 - BITS, 10), all other bits 0 (mask = field mask << (10 - BITS), both halves)")
+        lines.append("  template <int P>")
+        lines.append("  __device__ __forceinline__ static uint32_t sub_pair(const uint32_t (&w)[%d], uint32_t mask) {" % bits)
+        for p, pl in enumerate(pairs):
+            x = expr_build(pl["build"])
+            t = pl["shift"] + pl["e"] - (10 - bits)
+            if t > 0:
+                x = "(%s >> %d)" % (x, t)
+            elif t < 0:
+                x = "(%s << %d)" % (x, -t)
+            lines.append("    %sif constexpr (P == %d) return %s & mask;" % ("" if p == 0 else "else ", p, x))
         lines.append("    else return 0u;")
         lines.append("  }")
         lines.append("};")

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
@@ -94,11 +95,13 @@ void bench(const char* name, double bytes, int copies, F launch) {
          bytes / avg * 1e-3);
 }
 
-int main() {
-  const uint32_t K_ROWS = 512, N = 11008;  // 4-bit 4096 x 11008: 512 packed rows of 11008 words
+int main(int argc, char** argv) {
+  // default: 4-bit 4096 x 11008 = 512 packed rows of 11008 words; `stream_floor 1024 28672` = 8192 x 28672
+  const uint32_t K_ROWS = argc > 2 ? (uint32_t)atoi(argv[1]) : 512, N = argc > 2 ? (uint32_t)atoi(argv[2]) : 11008;
   const size_t words = (size_t)K_ROWS * N;
   const double bytes = words * 4.0;
-  const int copies = 26;  // > 512 MB
+  const int copies = (int)((600e6 + bytes - 1) / bytes) + 1;  // > 512 MB
+  printf("# %u packed rows x %u words = %.1f MB per launch, %d copies\n", K_ROWS, N, bytes * 1e-6, copies);
   uint32_t* w;
   uint32_t* out;
   hipMalloc(&w, words * 4 * copies);

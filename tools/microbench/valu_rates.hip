@@ -23,7 +23,10 @@ __global__ void __launch_bounds__(1024) rate(uint64_t* out, int iters, uint32_t 
   f4 c4[4];
   for (int i = 0; i < 16; ++i) { acc[i] = (float)i; u[i] = seed * (i + 1) + threadIdx.x; p2[i] = f2{(float)i, 1.f}; }
   for (int i = 0; i < 4; ++i) c4[i] = f4{0, 0, 0, 0};
-  uint32_t a = seed + threadIdx.x, b = 0x3c003c00u, m = 0x000f000fu, g = 0x64006400u;
+  uint32_t a = seed + threadIdx.x, b = 0x3c003c00u, m = 0x000f000fu, g = 0x64006400u, sub = 0x00f000f0u & (seed * 77u + threadIdx.x * 16u);
+  uint64_t d64[8];
+  for (int i = 0; i < 8; ++i) d64[i] = (uint64_t)seed * (i + 3) + threadIdx.x;
+  asm volatile("" : "+v"(sub));
   h8 fa, fb;
   for (int i = 0; i < 8; ++i) { fa[i] = (_Float16)(float)(threadIdx.x & 7); fb[i] = (_Float16)1.0f; }
   asm volatile("" : "+v"(a), "+v"(b), "+v"(g));
@@ -80,6 +83,66 @@ __global__ void __launch_bounds__(1024) rate(uint64_t* out, int iters, uint32_t 
 #define X(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(a), "v"(b));
       REP16(X)
 #undef X
+    } else if constexpr (OP == 12) {
+#define X(i) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 13) {
+#define X(i) asm volatile("v_lshrrev_b32 %0, 4, %1" : "=v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 14) {
+#define X(i) asm volatile("v_lshlrev_b64 %0, 4, %1" : "=v"(d64[i & 7]) : "v"(d64[(i + 1) & 7]));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 15) {  // pk_fma with a subnormal multiplicand (0x000f000f-style)
+#define X(i) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(u[i]) : "v"(sub), "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 16) {
+#define X(i) asm volatile("v_bfe_u32 %0, %1, 4, 4" : "=v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 17) {
+#define X(i) asm volatile("v_lshl_or_b32 %0, %1, 4, %0" : "+v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 18) {
+#define X(i) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(acc[i]), "v"(acc[(i + 1) & 15]));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 19) {
+#define X(i) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(acc[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 20) {
+#define X(i) asm volatile("v_pk_lshrrev_b16 %0, 4, %1" : "=v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 21) {
+#define X(i) asm volatile("v_or_b32 %0, %1, %0" : "+v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 22) {
+#define X(i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 23) {
+#define X(i) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 24) {
+#define X(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(b));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 25) {
+#define X(i) asm volatile("v_alignbit_b32 %0, %1, %0, 4" : "+v"(u[i]) : "v"(a));
+      REP16(X)
+#undef X
+    } else if constexpr (OP == 26) {
+#define X(i) asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(u[i]) : "v"(a), "v"(acc[i]), "v"(acc[(i + 1) & 15]));
+      REP16(X)
+#undef X
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -87,6 +150,7 @@ __global__ void __launch_bounds__(1024) rate(uint64_t* out, int iters, uint32_t 
   float s = 0;
   for (int i = 0; i < 16; ++i) s += acc[i] + (float)u[i] + p2[i].x + p2[i].y;
   for (int i = 0; i < 4; ++i) s += c4[i].x + c4[i].y + c4[i].z + c4[i].w;
+  for (int i = 0; i < 8; ++i) s += (float)d64[i];
   if (s == 12345.678f) out[0] = 1;  // keep everything live
   if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
@@ -126,6 +190,21 @@ int main() {
   run<3>("v_fma_mix_f32", 16);
   run<4>("v_pk_fma_f32", 16);
   run<9>("v_cvt_f32_f16", 16);
+  run<12>("v_and_b32 (VOP2)", 16);
+  run<21>("v_or_b32 (VOP2)", 16);
+  run<22>("v_add_u32 (VOP2)", 16);
+  run<13>("v_lshrrev_b32 (VOP2)", 16);
+  run<20>("v_pk_lshrrev_b16", 16);
+  run<14>("v_lshlrev_b64", 16);
+  run<25>("v_alignbit_b32", 16);
+  run<16>("v_bfe_u32", 16);
+  run<17>("v_lshl_or_b32", 16);
+  run<15>("v_pk_fma_f16, subnormal multiplicand", 16);
+  run<23>("v_pk_mul_f16", 16);
+  run<24>("v_mul_f32 (VOP2)", 16);
+  run<18>("v_cvt_pk_f16_f32", 16);
+  run<19>("v_cvt_f32_ubyte1", 16);
+  run<26>("v_fma_mixlo_f16", 16);
   run<7>("v_mfma_f32_16x16x32_f16", 16);
   run<8>("mfma + 13 pk_fma interleaved (x4)", 56);
   return 0;

@@ -3,6 +3,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "xbit_host.h"
 
@@ -30,6 +33,51 @@ int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, vo
 }
 
 static std::atomic<int> g_gemv_variant{-1};
+static std::atomic<int> g_gemv_split{0};
+int gemv_split_override() { return g_gemv_split.load(std::memory_order_relaxed); }
+
+namespace {
+constexpr size_t kPartialFloats = (size_t)1 << 20;  // 4 MiB of fp32 partial sums per stream
+constexpr size_t kCounterSlots = (size_t)1 << 14;
+std::mutex g_ws_mutex;
+std::map<std::pair<int, hipStream_t>, GemvWorkspace> g_ws;  // never freed: lives as long as the process
+}  // namespace
+
+bool gemv_workspace(hipStream_t stream, GemvWorkspace* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  auto it = g_ws.find({dev, stream});
+  if (it != g_ws.end()) {
+    *out = it->second;
+    return out->partial != nullptr;
+  }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;  // not remembered: a later call outside the capture allocates
+  }
+  GemvWorkspace ws;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&ws.partial), kPartialFloats * sizeof(float)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&ws.counters), kCounterSlots * sizeof(uint32_t)) == hipSuccess &&
+            hipMemsetAsync(ws.counters, 0, kCounterSlots * sizeof(uint32_t), stream) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (ws.partial) (void)hipFree(ws.partial);
+    if (ws.counters) (void)hipFree(ws.counters);
+    ws = GemvWorkspace{};
+  } else {
+    ws.partial_floats = kPartialFloats;
+    ws.counter_slots = kCounterSlots;
+  }
+  g_ws[{dev, stream}] = ws;  // a failed allocation is remembered too: no retry storm
+  *out = ws;
+  return ok;
+}
+
 static std::atomic<uint64_t*> g_gemv_trace{nullptr};
 int gemv_variant_override() { return g_gemv_variant.load(std::memory_order_relaxed); }
 uint64_t* gemv_trace_buffer() { return g_gemv_trace.load(std::memory_order_relaxed); }
@@ -113,6 +161,10 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
   p.tiles = 0;
   p.batches = 0;
   p.trace = xbit::gemv_trace_buffer();
+  p.splits = 1;
+  p.bps = 0;
+  p.partial = nullptr;
+  p.counters = nullptr;
   return xbit::launch_gemv(p, bits, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -147,6 +199,8 @@ int xbit_profile_last_ms(float* ms) {
 /* Tuning hook, deliberately NOT in the public header: selects a GEMV launch-shape variant for
  * sweeps (tools/gemv_sweep.py); -1 restores automatic selection. */
 void xbit_debug_set_gemv_variant(int v) { xbit::g_gemv_variant.store(v, std::memory_order_relaxed); }
+/* Forces the split-K factor of eligible launches (<= 0: automatic; 1: never split). */
+void xbit_debug_set_gemv_split(int splits) { xbit::g_gemv_split.store(splits, std::memory_order_relaxed); }
 /* Device buffer (8 x uint64 per wave) that the stamped measurement build (variants 41+) fills. */
 void xbit_debug_set_gemv_trace(void* device_buffer) { xbit::g_gemv_trace.store(static_cast<uint64_t*>(device_buffer), std::memory_order_relaxed); }
 

@@ -142,7 +142,41 @@ struct Unpack {
       return OddUnpack<BITS>::template pair<P>(w, k);
     }
   }
+
+  // --- subnormal form (the fast path) ---------------------------------------------------------
+  // A field moved to mantissa bits [kSubE, 10) of an otherwise zero fp16 IS the subnormal
+  // q * 2^(kSubE - 24): no exponent to splice in and no 1024 to subtract afterwards, so
+  //   w = fma(Qsub, s * 2^(24 - kSubE), -zs)        (product exact inside the fma = q * s)
+  // is the reference's single-rounded hfma in ONE packed op per pair.  Extraction is one shift and
+  // one v_and_b32 per pair, both full-rate VOP2 (1.45 cycles per wave-instruction against 3.5 for
+  // v_and_or_b32 / v_pk_*: profiles/r01/valu_issue_rates.txt).  Valid while the pre-scaled scale is
+  // finite in fp16, |s| <= 65504 * 2^-(14 + BITS) (a quantisation range of about 4.0 for every
+  // BITS); the caller checks that per wave and otherwise takes the spliced form above.
+  static constexpr int kSubE = 10 - BITS;
+  static constexpr int kSubScaleLog2 = 24 - kSubE;  // 14 + BITS
+  static constexpr uint32_t kSubMask2 = (kMask << kSubE) * 0x00010001u;
+
+  template <int P>
+  __device__ __forceinline__ static uint32_t sub_pair(const uint32_t (&w)[BITS], uint32_t mask) {
+    if constexpr (kPow2) {
+      constexpr int c = P / kPerHalf, pos = (P % kPerHalf) * BITS, t = pos - kSubE;
+      if constexpr (t > 0) return (w[c] >> t) & mask;
+      else if constexpr (t < 0) return (w[c] << (-t)) & mask;
+      else return w[c] & mask;
+    } else {
+      return OddUnpack<BITS>::template sub_pair<P>(w, mask);
+    }
+  }
 };
+
+// Pre-scaled scale for the subnormal form: fp16(s * 2^(14 + BITS)), exact (a pure exponent shift,
+// subnormal s included) whenever it is finite; `ok` is false when it is not (or s is NaN/Inf).
+template <int BITS>
+__device__ __forceinline__ _Float16 sub_scale(_Float16 s, bool& ok) {
+  const float sf = (float)s * (float)(1u << Unpack<BITS>::kSubScaleLog2);
+  ok = __builtin_fabsf(sf) <= 65504.0f;
+  return (_Float16)sf;
+}
 
 // w2 = hfma2(half2(q), s2, nzs2) from the spliced pattern Q = (1024 + q * 2^E) x2 (see Unpack)
 template <int E = 0>

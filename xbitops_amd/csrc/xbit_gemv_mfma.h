@@ -91,6 +91,7 @@ struct RowLoad {
 //   NT    nontemporal weight loads   GUARD  false when the shape needs no edge handling at all
 //   ABLATE (measurement builds only): 1 = no weight loads (registers stand in), 2 = no
 //          unpack/dequant/MFMA (loaded words are xor-folded), 3 = both (all three: wrong results);
+//          4 = correct results, always the spliced (pre-subnormal) unpack, for A/B timing;
 //          8 = correct results plus per-wave s_memrealtime stamps written to p.trace
 //   LA   load lookahead in row loads (0 = issue the whole batch up front).  A wave issues in order,
 //        and the CU's memory pipeline back-pressures: a wave that queues all its loads first sits at
@@ -98,8 +99,13 @@ struct RowLoad {
 //        back long ago.  With LA > 0 the row loads are woven into the compute stream: before MFMA
 //        step s the loads needed by steps <= s + LA are issued, so a wave computes while its later
 //        rows are in flight and never holds more than LA + 1 queue slots.
-template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0>
+//   SPLIT  split-K: workgroup (tile, split) sums k-batches [split*bps, (split+1)*bps) only; the
+//        partial sums meet in a workspace and the last workgroup of a tile to arrive adds them in
+//        split order (so the result does not depend on the arrival order) and writes the output.
+//        For few column tiles and long K (down-projections), where whole-K tiles leave CUs idle.
+template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) {
+  static_assert(!SPLIT || GUARD, "split-K launches use the guarded build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 16 || NL == 8, "lanes along N");
   constexpr int LK = 64 / NL;            // k-slots per wave
@@ -124,13 +130,18 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   __shared__ __attribute__((aligned(16))) float s_red[NW * RS * MT * CN];
 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / NL, nl = lane % NL;
-  const uint32_t tile = xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
+  const uint32_t tile = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t b_begin = SPLIT ? split * p.bps : 0u;
+  const uint32_t b_end = SPLIT ? (b_begin + p.bps < p.batches ? b_begin + p.bps : p.batches) : p.batches;
+  const uint32_t k_end = SPLIT ? (b_end * (uint32_t)(UB * 32) < p.k ? b_end * (uint32_t)(UB * 32) : p.k) : p.k;  // activations beyond: 0
   const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
   const bool col_ok = GUARD ? col < p.n : true;  // n % CPL == 0 is NOT required: stores are per column
   const uint32_t m0 = blockIdx.y * MT;
   uint32_t* const my_act = s_act + wv * ACT_DW;
   const int arow = nl % MT;  // activation row this lane feeds to its row block of the A tile
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
+  const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const uint32_t row_bytes = p.n * 4u;  // one packed row
 
   const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
@@ -144,10 +155,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABLATE & 8) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
-  for (uint32_t b0 = 0; b0 < p.batches; b0 += T) {
+  for (uint32_t b0 = b_begin; b0 < b_end; b0 += T) {
     const uint32_t wb = b0 + wv * LK;  // first batch of this wave in this sweep
     const uint32_t bt = wb + kl;       // this lane's batch
-    const bool active = GUARD ? (col_ok && bt < p.batches) : true;
+    const bool active = GUARD ? (col_ok && bt < b_end) : true;
 
     // (1) activation slice of this wave (oldest loads in the vmcnt queue).  Rows >= M fall off the
     //     end of the buffer and read 0; k >= K must be forced out of range (it would alias row m+1).
@@ -158,11 +169,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
       const int mi = s / (LK * UB * (32 / CHK)), ch = s % (LK * UB * (32 / CHK));
       const uint32_t k0 = wb * (uint32_t)(UB * 32) + (uint32_t)(ch * CHK);
       uint32_t aoff = ((m0 + mi) * p.k + k0) * 2u;
-      if (GUARD && (k0 >= p.k || m0 + mi >= p.m)) aoff = kOob;  // k % 8 == 0: chunks are all-in or all-out
+      if (GUARD && (k0 >= k_end || m0 + mi >= p.m)) aoff = kOob;  // k % 8 == 0: chunks are all-in or all-out
 #pragma unroll
       for (int q = 0; q < CPT; ++q) {
         uint32_t o = aoff + 16u * q;
-        if (GUARD && CPT > 1 && k0 + 8u * q >= p.k) o = kOob;
+        if (GUARD && CPT > 1 && k0 + 8u * q >= k_end) o = kOob;
         hraw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
       }
     }
@@ -270,56 +281,75 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // (5) per-column dequant constants
-    half2_t s2[CPL], nzs2[CPL];
+    // (5) per-column dequant constants.  The subnormal form (xbit_device.h) needs the scale times
+    //     2^(14 + BITS) to be finite in fp16; if any lane of the wave holds a scale too large for
+    //     that (or NaN/Inf) the whole wave takes the spliced form for this batch - same W, bit for bit.
+    half2_t s2[CPL], nzs2[CPL], ss2[CPL];
+    bool sub_ok = true;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const _Float16 s = as_h((uint16_t)sbits[c]);
       const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + p.bias;
       s2[c] = splat(s);
       nzs2[c] = splat(neg_zero_times_scale(z, s));
+      bool ok;
+      ss2[c] = splat(sub_scale<BITS>(s, ok));
+      sub_ok = sub_ok && ok;
     }
+    const bool fast = (ABLATE & 4) ? false : __builtin_amdgcn_ballot_w64(!sub_ok) == 0;  // wave-uniform
 
     // (6) unpack + dequantise on the VALU, multiply-accumulate on the matrix pipe; the loads of
     //     the steps LA ahead are issued in front of each step
-    static_for<UB * 4>([&](auto step_c) {
-      constexpr int step = decltype(step_c)::value, j = step / 4, oct = step % 4;
-      if constexpr (LA > 0 && step > 0) {
-        issue_range(std::integral_constant<int, LS::issued_before(step - 1)>{}, std::integral_constant<int, LS::issued_before(step)>{});
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      uint32_t wc[CPL][BITS];
-#pragma unroll
-      for (int c = 0; c < CPL; ++c)
-#pragma unroll
-        for (int i = 0; i < BITS; ++i) wc[c][i] = w[j][i].v[c];
-
-      if constexpr (ABLATE & 2) {
-        if constexpr (oct == 0) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c)
-#pragma unroll
-            for (int i = 0; i < BITS; ++i) acc[c][0] += __builtin_bit_cast(float, wc[c][i] & 0x3FFFFFFFu);
+    auto run_steps = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
+      static_for<UB * 4>([&](auto step_c) {
+        constexpr int step = decltype(step_c)::value, j = step / 4, oct = step % 4;
+        if constexpr (LA > 0 && step > 0) {
+          issue_range(std::integral_constant<int, LS::issued_before(step - 1)>{}, std::integral_constant<int, LS::issued_before(step)>{});
+          __builtin_amdgcn_sched_barrier(0);
         }
-      } else {
-        const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + (arow * LK + kl) * KLS + j * 16 + 4 * oct);
-        const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
-        u32x4_t braw[CPL];
-        static_for<4>([&](auto e_c) {
-          constexpr int e = decltype(e_c)::value;
-          constexpr int pr = 4 * oct + e;
-          uint32_t Q[CPL];
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template pair<pr>(wc[c], uk);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]));
-        });
+        uint32_t wc[CPL][BITS];
 #pragma unroll
         for (int c = 0; c < CPL; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
-      }
-      if constexpr (LA > 0) __builtin_amdgcn_sched_barrier(0);
-    });
+#pragma unroll
+          for (int i = 0; i < BITS; ++i) wc[c][i] = w[j][i].v[c];
+
+        if constexpr (ABLATE & 2) {
+          if constexpr (oct == 0) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+#pragma unroll
+              for (int i = 0; i < BITS; ++i) acc[c][0] += __builtin_bit_cast(float, wc[c][i] & 0x3FFFFFFFu);
+          }
+        } else {
+          const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + (arow * LK + kl) * KLS + j * 16 + 4 * oct);
+          const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
+          u32x4_t braw[CPL];
+          static_for<4>([&](auto e_c) {
+            constexpr int e = decltype(e_c)::value;
+            constexpr int pr = 4 * oct + e;
+            uint32_t Q[CPL];
+            if constexpr (FAST) {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template sub_pair<pr>(wc[c], sub_mask);
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(__builtin_elementwise_fma(as_h2(Q[c]), ss2[c], nzs2[c]));
+            } else {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template pair<pr>(wc[c], uk);
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]));
+            }
+          });
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+        }
+        if constexpr (LA > 0) __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    if (fast) run_steps(std::true_type{});
+    else run_steps(std::false_type{});
     __builtin_amdgcn_wave_barrier();  // keep the next sweep's LDS writes behind these reads
   }
   if constexpr (ABLATE & 8) {
@@ -349,8 +379,35 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < NW * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
-    const uint32_t n_out = tile * CN + c, row = m0 + m;
-    if (!GUARD || (n_out < p.n && row < p.m)) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
+    if constexpr (SPLIT) {
+      // device-scope relaxed atomic store = write-through store (sc1): visible to every XCD once
+      // vmcnt retires it, without a release fence (which would write back the whole L2)
+      __hip_atomic_store(p.partial + (((size_t)blockIdx.y * p.tiles + tile) * p.splits + split) * (size_t)(MT * CN) + e, sum,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const uint32_t n_out = tile * CN + c, row = m0 + m;
+      if (!GUARD || (n_out < p.n && row < p.m)) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
+    }
+  }
+  if constexpr (SPLIT) {
+    __shared__ uint32_t s_last;
+    uint32_t* const ticket = p.counters + (size_t)blockIdx.y * p.tiles + tile;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have reached device scope
+    __syncthreads();                                   // ... and so have every wave's
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == p.splits) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+      const float* part = p.partial + ((size_t)blockIdx.y * p.tiles + tile) * p.splits * (size_t)(MT * CN);
+      for (int e = tid; e < MT * CN; e += 64 * NW) {
+        const int m = e / CN, c = e % CN;
+        float sum = 0.f;
+        for (uint32_t sp = 0; sp < p.splits; ++sp)
+          sum += __hip_atomic_load(part + (size_t)sp * (MT * CN) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n_out = tile * CN + c, row = m0 + m;
+        if (n_out < p.n && row < p.m) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
+      }
+      if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
   }
   if constexpr (ABLATE & 8) {
     stamp[5] = __builtin_amdgcn_s_memrealtime();
@@ -372,14 +429,72 @@ constexpr int lookahead_for() {
 
 template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, int LA = kLookahead>
 int launch_one(GemvParams p, hipStream_t stream) {
-  constexpr int CN = NL * CPL, T = (64 / NL) * NW;
+  constexpr int CN = NL * CPL;
   p.tiles = (p.n + CN - 1) / CN;
   const uint32_t kblocks = (p.k + 31) / 32;
   p.batches = (kblocks + UB - 1) / UB;
   dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * NW);
-  const bool exact = (p.k % (32u * UB) == 0) && (p.batches % T == 0) && (p.n % CN == 0) && (p.m % MT == 0);
-  if (exact) return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, NT, false, 0, LA>, grid, block, stream, p);
+  // One build per launch shape, edge handling always on: the unguarded build measured the same
+  // (6.7 vs 6.8 us on 4096x11008) and doubled the number of kernels to compile.
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, NT, true, 0, LA>, grid, block, stream, p);
+}
+
+// tuning variants are M = 1 launches of one shape (tools/gemv_sweep.py)
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int LA = lookahead_for<BITS>()>
+int launch_m1(const GemvParams& p, hipStream_t stream) {
+  return launch_one<BITS, UB, CPL, NL, NW, 1, NT, LA>(p, stream);
+}
+
+// split-K launch (see SPLIT): grid.x = tiles * splits
+template <int BITS, int UB, int CPL, int NW, int MT>
+int launch_split(GemvParams p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws) {
+  constexpr int CN = 16 * CPL;
+  p.tiles = (p.n + CN - 1) / CN;
+  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
+  p.splits = splits;
+  p.bps = (p.batches + splits - 1) / splits;
+  p.partial = ws.partial;
+  p.counters = ws.counters;
+  dim3 grid(p.tiles * splits, (p.m + MT - 1) / MT), block(64 * NW);
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, MT, false, true, 0, lookahead_for<BITS>(), true>, grid, block, stream, p);
+}
+
+template <int BITS, int UB, int CPL, int NW>
+int launch_split_rows(const GemvParams& p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws) {
+  if (p.m == 1) return launch_split<BITS, UB, CPL, NW, 1>(p, stream, splits, ws);
+  return launch_split<BITS, UB, CPL, NW, 4>(p, stream, splits, ws);
+}
+
+// Split-K plan.  Measured on MI355X (profiles/r01/sweep_split_k.txt): the reduction tail (partial
+// store -> ticket -> partial loads, three trips to the device coherence point) costs ~3 us, so
+// splitting pays only when N is small (<= 80 tiles of 64 columns) AND K is long (>= 14336):
+// 28672x4096 18.5 -> 15.5 us, 28672x2048 17.0 -> 11.0, 32768x1024 17.6 -> 9.5; it loses on
+// 11008x4096 and on everything with N >= 8192.  tiles x splits ~ 256 workgroups of 8 waves; 64-column
+// tiles unless that needs more than 8 splits.  splits == 0: do not split.
+struct SplitPlan {
+  int cpl = 0;
+  uint32_t splits = 0;
+};
+inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits) {
+  SplitPlan plan;
+  if (p.m > 4 || forced_splits == 1) return plan;
+  const uint32_t kblocks = (p.k + 31) / 32, batches = (kblocks + ub - 1) / ub;
+  const uint32_t tiles64 = (p.n + 63) / 64, tiles32 = (p.n + 31) / 32;
+  if (forced_splits <= 0 && !(tiles64 <= 80 && kblocks >= 448)) return plan;
+  plan.cpl = tiles64 * 8 >= 200 ? 4 : 2;
+  const uint32_t tiles = plan.cpl == 4 ? tiles64 : tiles32;
+  uint32_t splits = forced_splits > 0 ? (uint32_t)forced_splits : (256u + tiles / 2) / tiles;
+  if (splits > 8u && forced_splits <= 0) splits = 8u;
+  if (splits > batches / 8u) splits = batches / 8u;  // at least 8 batches per split
+  if (splits > 64u) splits = 64u;
+  plan.splits = splits >= 2u ? splits : 0u;
+  return plan;
+}
+
+template <int BITS, int UB>
+int launch_plan(const GemvParams& p, hipStream_t stream, const SplitPlan& plan, const GemvWorkspace& ws) {
+  if (plan.cpl == 4) return launch_split_rows<BITS, UB, 4, 8>(p, stream, plan.splits, ws);
+  return launch_split_rows<BITS, UB, 2, 8>(p, stream, plan.splits, ws);
 }
 
 // measurement-only launches (M = 1, plain loads): ablated or stamped builds, see ABLATE
@@ -425,14 +540,12 @@ inline int pick_cpl(uint32_t n) {
   return best;
 }
 
-template <int BITS, int UB, int NW>
+template <int BITS, int UB, int NW, bool NT = false>
 int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl) {
   switch (cpl) {
-    // plain (not nontemporal) loads: equal to nt when the weights come from HBM, ~8 % faster when
-    // they are still in the Infinity Cache (measured: profiles/r01/sweep_*.txt)
-    case 4: return launch_rows<BITS, UB, 4, 16, NW, false>(p, stream);
-    case 3: return launch_rows<BITS, UB, 3, 16, NW, false>(p, stream);
-    default: return launch_rows<BITS, UB, 2, 16, NW, false>(p, stream);
+    case 4: return launch_rows<BITS, UB, 4, 16, NW, NT>(p, stream);
+    case 3: return launch_rows<BITS, UB, 3, 16, NW, NT>(p, stream);
+    default: return launch_rows<BITS, UB, 2, 16, NW, NT>(p, stream);
   }
 }
 
@@ -442,56 +555,71 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
   const uint32_t kblocks = (p.k + 31) / 32;
   const int cpl = pick_cpl(p.n);
   if (p.groupsize % (32u * UBMAX) == 0) {
-    switch (variant) {  // lookahead sweep, every bit-width (48-column tiles)
-      case 101: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 2>(p, stream);
-      case 102: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 6>(p, stream);
-      case 103: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 8>(p, stream);
-      case 104: return launch_rows<BITS, UBMAX, 3, 16, 8, false, 4>(p, stream);
-      default: break;
-    }
-    if constexpr (BITS == 4) {  // tuning variants exist for the headline bit-width only
+    if (variant >= 0 && p.m == 1) {  // tuning hooks (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
-        case 11: return launch_rows<BITS, 4, 2, 16, 8, true>(p, stream);
-        case 12: return launch_rows<BITS, 4, 3, 16, 8, true>(p, stream);
-        case 21: return launch_rows<BITS, 4, 2, 16, 8, false>(p, stream);
-        case 22: return launch_rows<BITS, 4, 4, 16, 8, false>(p, stream);
-        case 91: return launch_one<BITS, 2, 3, 16, 4, 16, false>(p, stream);
-        case 92: return launch_one<BITS, 2, 3, 16, 8, 16, false>(p, stream);
-        case 93: return launch_one<BITS, 4, 3, 16, 8, 16, false>(p, stream);
-        case 94: return launch_one<BITS, 1, 3, 16, 8, 16, false>(p, stream);
-        case 95: return launch_one<BITS, 1, 3, 16, 16, 16, false>(p, stream);
-        case 96: return launch_one<BITS, 2, 4, 16, 8, 16, false>(p, stream);
-        case 28: return launch_rows<BITS, 4, 2, 8, 8, false>(p, stream);
-        case 29: return launch_rows<BITS, 4, 4, 8, 8, false>(p, stream);
-        case 30: return launch_rows<BITS, 4, 3, 8, 8, false>(p, stream);
-        case 23: return launch_rows<BITS, 4, 2, 16, 16, false>(p, stream);
-        case 24: return launch_rows<BITS, 4, 3, 16, 16, false>(p, stream);
-        case 25: return launch_rows<BITS, 4, 4, 16, 16, false>(p, stream);
-        case 26: return launch_rows<BITS, 4, 4, 16, 4, false>(p, stream);
-        case 27: return launch_rows<BITS, 4, 2, 16, 4, false>(p, stream);
-        case 13: return launch_rows<BITS, 4, 4, 16, 8, true>(p, stream);
-        case 14: return launch_rows<BITS, 2, 3, 16, 16, true>(p, stream);
-        case 15: return launch_rows<BITS, 4, 3, 16, 8, false>(p, stream);
-        case 16: return launch_rows<BITS, 4, 3, 16, 8, true, 0>(p, stream);
-        case 17: return launch_rows<BITS, 4, 3, 16, 8, true, 2>(p, stream);
-        case 18: return launch_rows<BITS, 4, 3, 16, 8, true, 6>(p, stream);
-        case 19: return launch_rows<BITS, 4, 3, 16, 8, true, 8>(p, stream);
-        case 20: return launch_rows<BITS, 2, 3, 16, 16, true, 2>(p, stream);
-        case 31: return launch_la<BITS, 4, 3, 16, 8, 1, kLookahead>(p, stream);
-        case 32: return launch_la<BITS, 4, 3, 16, 8, 2, kLookahead>(p, stream);
-        case 33: return launch_la<BITS, 4, 3, 16, 8, 3, kLookahead>(p, stream);
-        case 61: return launch_la<BITS, 2, 3, 16, 16, 8, kLookahead>(p, stream);
-        case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);
+        case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
+        case 106: return launch_la<BITS, UBMAX, 3, 16, 8, 0, lookahead_for<BITS>()>(p, stream);  // same launch, default unpack
         default: break;
       }
+      if constexpr (BITS == 4) {  // launch-shape variants exist for the headline bit-width only
+        switch (variant) {
+          case 21: return launch_m1<BITS, 4, 2, 16, 8, false>(p, stream);
+          case 15: return launch_m1<BITS, 4, 3, 16, 8, false>(p, stream);
+          case 22: return launch_m1<BITS, 4, 4, 16, 8, false>(p, stream);
+          case 23: return launch_m1<BITS, 4, 2, 16, 16, false>(p, stream);
+          case 24: return launch_m1<BITS, 4, 3, 16, 16, false>(p, stream);
+          case 25: return launch_m1<BITS, 4, 4, 16, 16, false>(p, stream);
+          case 11: return launch_m1<BITS, 4, 2, 16, 8, true>(p, stream);
+          case 12: return launch_m1<BITS, 4, 3, 16, 8, true>(p, stream);
+          case 13: return launch_m1<BITS, 4, 4, 16, 8, true>(p, stream);
+          case 28: return launch_m1<BITS, 4, 2, 8, 8, false>(p, stream);
+          case 39: return launch_m1<BITS, 2, 2, 8, 8, false>(p, stream);
+          case 16: return launch_m1<BITS, 4, 3, 16, 8, false, 0>(p, stream);  // lookahead sweep
+          case 17: return launch_m1<BITS, 4, 3, 16, 8, false, 2>(p, stream);
+          case 18: return launch_m1<BITS, 4, 3, 16, 8, false, 6>(p, stream);
+          case 19: return launch_m1<BITS, 4, 3, 16, 8, false, 8>(p, stream);
+          case 31: return launch_la<BITS, 4, 3, 16, 8, 1, kLookahead>(p, stream);  // no weight loads
+          case 32: return launch_la<BITS, 4, 3, 16, 8, 2, kLookahead>(p, stream);  // loads only
+          case 33: return launch_la<BITS, 4, 3, 16, 8, 3, kLookahead>(p, stream);  // neither
+          case 46: return launch_la<BITS, 4, 4, 16, 8, 1, kLookahead>(p, stream);
+          case 47: return launch_la<BITS, 4, 4, 16, 8, 2, kLookahead>(p, stream);
+          case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);  // stamped (tools/gemv_trace.py)
+          default: break;
+        }
+      }
     }
-    // Few, long tiles (e.g. the 8192x3584 shard of a 70B FFN on 8 GPUs: 112 tiles of 32 columns):
+    // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
+    {
+      SplitPlan plan = plan_split(p, UBMAX, gemv_split_override());
+      if ((variant == 202 || variant == 205) && plan.splits >= 2) {  // sweep hook: force the tile width
+        plan.cpl = variant == 202 ? 2 : 4;
+      } else if (variant >= 0) {
+        plan.splits = 0;  // another tuning variant was asked for
+      }
+      if (plan.splits >= 2) {
+        const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
+        const size_t floats = (size_t)mblocks * tiles * plan.splits * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
+        GemvWorkspace ws;
+        if (floats <= ((size_t)1 << 20) && (size_t)mblocks * tiles <= ((size_t)1 << 14) && gemv_workspace(stream, &ws) &&
+            floats <= ws.partial_floats && (size_t)mblocks * tiles <= ws.counter_slots)
+          return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
+      }
+    }
+    // Few tiles (e.g. the 8192x3584 shard of a 70B FFN on 8 GPUs: 112 tiles of 32 columns; 4096x4096):
     // halve the tile width (NL = 8: 16 columns, the MFMA's column slots split into two k-slots) so
-    // twice as many CUs get work.  Measured 7.6 -> 6.9 us on that shard; no gain at K = 4096.
-    if (cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 256 && p.m <= 8)
-      return launch_rows<BITS, UBMAX, 2, 8, 8, false>(p, stream);
-    // enough waves to cover K in one sweep when possible (T = 4*NW batches per sweep)
-    if (kblocks / UBMAX >= 64) return launch_cpl<BITS, UBMAX, 16>(p, stream, cpl);
+    // twice as many CUs get work, with 2 k-blocks per lane and sweep.  Measured: 8192x3584 7.6 -> 6.8 us,
+    // 4096x4096 5.4 -> 4.5, 11008x4096 11.2 -> 8.5 (profiles/r01/sweep_k_heavy_shapes.txt).
+    if (cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128 && p.m <= 8)
+      return launch_rows<BITS, (UBMAX > 2 ? 2 : UBMAX), 2, 8, 8, false>(p, stream);
+    // 16 waves when there is at most one workgroup per CU and K fills them in one sweep; otherwise
+    // 8-wave workgroups (several per CU, sweeping K): 8192x28672 26.2 -> 25.3 us, 28672x8192 28.1 -> 25.5
+    const uint32_t tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
+    if (kblocks / UBMAX >= 64 && tiles <= 240) return launch_cpl<BITS, UBMAX, 16>(p, stream, cpl);
+    // Weight loads are plain by default: equal to nontemporal when the weights come from HBM and ~8 %
+    // faster when they are still in the Infinity Cache (4096x11008).  Very large, wide layers cannot
+    // stay cached anyway and stream ~9 % faster nontemporal (8192x28672: 25.8 -> 23.4 us); long
+    // narrow ones (28672x8192) show no difference.  (profiles/r01/sweep_nt_large_shapes.txt)
+    if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) return launch_cpl<BITS, UBMAX, 8, true>(p, stream, cpl);
     return launch_cpl<BITS, UBMAX, 8>(p, stream, cpl);
   }
   if constexpr (UBMAX > 2) {

@@ -29,7 +29,25 @@ struct GemvParams {
   uint32_t tiles;    // column tiles (grid.x)
   uint32_t batches;  // k-batches of UB k-blocks
   uint64_t* trace;   // measurement builds only: per-wave s_memrealtime stamps (else nullptr)
+  // split-K launches only (few column tiles, long K): K is cut into `splits` ranges of `bps`
+  // batches, one workgroup each; partial sums meet in `partial`, the last workgroup to arrive
+  // (ticket in `counters`) adds them in split order and writes the fp16 result.
+  uint32_t splits, bps;
+  float* partial;      // [grid.y][tiles][splits][MT * CN] fp32
+  uint32_t* counters;  // [grid.y][tiles], zero between launches (the last arriver resets its ticket)
 };
+
+// Per-(device, stream) scratch for split-K launches: launches on one stream run in order, so they
+// can share it; different streams get their own.  Allocated on first use and kept.
+struct GemvWorkspace {
+  float* partial = nullptr;
+  uint32_t* counters = nullptr;
+  size_t partial_floats = 0;
+  size_t counter_slots = 0;
+};
+// false: no workspace for this stream (allocation failed, or the first use would fall inside a
+// stream capture, where allocation is not allowed) - the caller then launches without split-K.
+bool gemv_workspace(hipStream_t stream, GemvWorkspace* ws);
 
 // thread-local profiling state (xbit_profile_enable / xbit_profile_last_ms)
 struct ProfileState {
@@ -56,6 +74,7 @@ int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int vari
 
 // tuning hooks (tools/ only): variant < 0 = automatic; trace buffer for the stamped build
 int gemv_variant_override();
+int gemv_split_override();  // <= 0: automatic
 uint64_t* gemv_trace_buffer();
 
 }  // namespace xbit
