@@ -99,6 +99,24 @@ def pmc_traffic(workload_key: str):
     return best
 
 
+def rocprof_kernel_avg_us():
+    """Average duration of the GEMV kernel in the committed rocprofv3 --kernel-trace --stats summary
+    of this same command (profiles/rNN/bench_kernel_stats.csv, newest round), for comparison with
+    the live HIP-event figure.  None when there is no summary."""
+    import csv
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_kernel_stats.csv")), reverse=True):
+        try:
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if "gemv_mfma_kernel" in row["Name"]:
+                        return os.path.relpath(path, ROOT), round(float(row["AverageNs"]) / 1e3, 3)
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
+
+
 def main():
     args = parse_args()
     import torch
@@ -279,6 +297,8 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic[1]["traffic_bytes_per_launch"] if traffic else None,
+                "rocprof_avg_kernel_us": (rocprof_kernel_avg_us() or (None, None))[1],
+                "rocprof_source": ((rocprof_kernel_avg_us() or (None, None))[0] or "") + ": rocprofv3 --kernel-trace --stats of this command; averages cold, graph and cache-warm launches and runs ~5-10 % slower under the profiler",
                 "traffic_source": (traffic[0] + ": rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, bytes per launch") if traffic else None,
                 "algorithmic_bytes": nbytes,
                 "kernel": "gemv_mfma_kernel<4,...>", "avg_kernel_us": round(cold_avg * 1e3, 3),
