@@ -126,8 +126,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   constexpr int NTASK = MT * LK * UB * (32 / CHK);
   constexpr int ROUNDS = (NTASK + 63) / 64;
 
-  __shared__ __attribute__((aligned(16))) uint32_t s_act[NW * ACT_DW];
-  __shared__ __attribute__((aligned(16))) float s_red[NW * RS * MT * CN];
+  // 16-row passes: the reduction scratch reuses the activation region (one extra barrier), which
+  // is what lets 4 k-blocks per lane fit in the 160 KB of LDS (139 KB of activations at NW = 8)
+  constexpr bool ALIAS = MT >= 16;
+  constexpr int RED_DW = NW * RS * MT * CN;
+  constexpr int LDS_DW = ALIAS ? (NW * ACT_DW > RED_DW ? NW * ACT_DW : RED_DW) : NW * ACT_DW + RED_DW;
+  __shared__ __attribute__((aligned(16))) uint32_t s_lds[LDS_DW];
+  uint32_t* const s_act = s_lds;
+  float* const s_red = reinterpret_cast<float*>(s_lds + (ALIAS ? 0 : NW * ACT_DW));
 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / NL, nl = lane % NL;
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
@@ -359,6 +365,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  if constexpr (ALIAS) __syncthreads();  // every wave is done reading its activations
   // D[drow][slot]: drow = 4*(lane>>4) + r lives in register r of lane (lane>>4, slot = lane&15).
   // Keep the quadrant where the row block equals the slot's k-slot, then sum over k-slots and waves.
   {
@@ -515,8 +522,7 @@ int launch_rows(const GemvParams& p, hipStream_t stream) {
   // 8-16 rows: the staged activation tile is 8-16x larger (LDS: NW*MT*4*(UB*16+4)*4 bytes, 139 KB
   // at UB = 4, NW = 8, MT = 16).  Measured on 4096x11008 w4 M=16: NW = 8 is 9.0-9.3 us, NW = 4 11.0 us.
   if (p.m <= 8) return launch_one<BITS, UB, CPL, NL, 8, 8, NT, LA>(p, stream);
-  constexpr int UB16 = UB > 2 ? 2 : UB;  // keeps activations + reduction scratch under the 160 KB of LDS at every CPL
-  return launch_one<BITS, UB16, CPL, 16, 8, 16, NT, LA>(p, stream);
+  return launch_one<BITS, UB, CPL, 16, 8, 16, NT, LA>(p, stream);
 }
 
 template <int BITS>
