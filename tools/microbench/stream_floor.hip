@@ -14,6 +14,7 @@
 #include <vector>
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void k_empty(uint32_t* out) {
@@ -36,6 +37,9 @@ __global__ void __launch_bounds__(64 * NW) k_tile(const uint32_t* __restrict__ w
       if constexpr (W == 8) {
         u32x2 t = NT ? __builtin_nontemporal_load((const u32x2*)src) : *(const u32x2*)src;
         v[i][0] = t.x; v[i][1] = t.y;
+      } else if constexpr (W == 12) {
+        u32x3 t = NT ? __builtin_nontemporal_load((const u32x3*)src) : *(const u32x3*)src;
+        v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z;
       } else if constexpr (W == 16) {
         u32x4 t = NT ? __builtin_nontemporal_load((const u32x4*)src) : *(const u32x4*)src;
         v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
@@ -130,7 +134,10 @@ int main(int argc, char** argv) {
   TILE_CASE("tile 8B x16lanes(32col) NW8 16 loads nt", 8, 16, 8, 16, true)
   TILE_CASE("tile 8B x16lanes(32col) NW8 16 loads", 8, 16, 8, 16, false)
   TILE_CASE("tile 8B x16lanes(32col) NW16 8 loads nt", 8, 16, 16, 8, true)
+  TILE_CASE("tile 12B x16lanes(48col) NW8 16 loads nt", 12, 16, 8, 16, true)
+  TILE_CASE("tile 12B x16lanes(48col) NW8 16 loads", 12, 16, 8, 16, false)
   TILE_CASE("tile 16B x16lanes(64col) NW8 16 loads nt", 16, 16, 8, 16, true)
+  TILE_CASE("tile 16B x16lanes(64col) NW8 16 loads", 16, 16, 8, 16, false)
   TILE_CASE("tile 16B x16lanes(64col) NW16 8 loads nt", 16, 16, 16, 8, true)
   TILE_CASE("tile 16B x8lanes(32col) NW4 16 loads nt", 16, 8, 4, 16, true)
   TILE_CASE("tile 16B x8lanes(32col) NW8 8 loads nt", 16, 8, 8, 8, true)
