@@ -18,8 +18,8 @@ namespace xbit {
 
 namespace {
 
-constexpr int kDqLanesN = 16;  // lanes along N (x 8 columns = 128 columns, 256 B of output row)
-constexpr int kDqLanesK = 16;  // k-blocks per workgroup
+constexpr int kDqLanesN = 64;  // lanes along N (x 8 columns = 512 columns: a wave stores 1 KB of one output row)
+constexpr int kDqLanesK = 4;   // k-blocks per workgroup (one per wave)
 constexpr int kDqThreads = kDqLanesN * kDqLanesK;
 
 template <int BITS, bool GROUP_PER_BLOCK>
