@@ -147,7 +147,9 @@ def test_gemv_row_counts_and_tile_widths(bits, cuda_device):
         y = run_gemv(p, 1, cuda_device)
         y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, 1024, 1, oracle.RNE)
         assert_gemv_close(y, y_ref, "bits=%d m=%d" % (bits, m))
-    for k, n, m in ((256, 8192, 1), (512, 11008, 1), (512, 11008, 4), (256, 4096 + 64, 2), (8192, 50, 1), (8192 + 64, 130, 3)):
+    # ... and the 128-column tiles of very wide layers (n >= 25600), whole and ragged, 1..8 rows, K sweeps
+    for k, n, m in ((256, 8192, 1), (512, 11008, 1), (512, 11008, 4), (256, 4096 + 64, 2), (8192, 50, 1), (8192 + 64, 130, 3),
+                    (4096, 25600, 1), (4096 + 256, 25600 + 34, 3), (512, 32000, 8), (256, 28672, 2)):
         p = synth.make_problem(k, n, bits, 128, m=m, seed=bits * 37 + n)
         y = run_gemv(p, 0, cuda_device)
         y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, k, 0, oracle.RNE)

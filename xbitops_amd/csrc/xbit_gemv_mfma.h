@@ -107,16 +107,18 @@ template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD
 __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) {
   static_assert(!SPLIT || GUARD, "split-K launches use the guarded build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
-  static_assert(NL == 16 || NL == 8, "lanes along N");
-  constexpr int LK = 64 / NL;            // k-slots per wave
-  constexpr int RS = 16 / NL;            // k-slots sharing one MFMA k-quad (row split of the A tile)
-  constexpr int RB = 16 / RS;            // rows per row block
+  static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
+  constexpr int LK = 64 / NL;                // k-slots per wave
+  constexpr int RS = NL < 16 ? 16 / NL : 1;  // NL = 8: k-slots sharing one MFMA k-octet (in different column slots)
+  constexpr int CS = NL > 16 ? NL / 16 : 1;  // NL = 32: column sets sharing the 16 column slots (in different k-octets)
+  constexpr int RB = 16 / (RS * CS);         // rows per row block of the A tile
   static_assert(MT == 1 || MT == 2 || MT == 4 || MT == 8 || MT == 16, "rows per pass");
   static_assert(MT <= RB, "rows per pass exceed the row block");
   constexpr int T = LK * NW;             // k-batches per workgroup sweep
   constexpr int CN = NL * CPL;           // columns per workgroup
   constexpr int KLS = UB * 16 + 4;       // dwords per (row, k-slot) activation slot (+4: bank spread)
-  constexpr int ACT_DW = MT * LK * KLS;  // staged activation dwords per wave
+  constexpr int ZERO_DW = CS > 1 ? KLS : 0;         // NL = 32: an all-zero slot for the lanes that feed the other column set
+  constexpr int ACT_DW = MT * LK * KLS + ZERO_DW;  // staged activation dwords per wave
   // Activation staging: a task is one chunk of CHK consecutive k (the span inside which the
   // unpacker pairs fields: a packed word for 2/4/8 bit), 16*CPT bytes, one lane per task.  Every
   // VMEM instruction costs the CU's address pipeline the same whatever its width, so the slice is
@@ -145,7 +147,21 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   const bool col_ok = GUARD ? col < p.n : true;  // n % CPL == 0 is NOT required: stores are per column
   const uint32_t m0 = blockIdx.y * MT;
   uint32_t* const my_act = s_act + wv * ACT_DW;
-  const int arow = nl % MT;  // activation row this lane feeds to its row block of the A tile
+  // A fragment of this lane = row (lane & 15), k-octet (lane >> 4) of the MFMA's A tile.
+  //   NL = 16: row = nl, octet = kl: the activations of row nl % MT for k-slot kl.
+  //   NL = 8:  row = (kl & 1)*8 + nl, octet = kl >> 1: k-slots 2g and 2g+1 share octet g but sit in column
+  //            slots 0-7 / 8-15; feeding them to row blocks 0-7 / 8-15 keeps their sums apart
+  //            (D[ks*8 + m][ks*8 + nl]; the off-diagonal quadrants are don't-care).
+  //   NL = 32: row = nl & 15, octet = 2*kl + (nl >> 4): column sets nl < 16 and nl >= 16 share the column
+  //            slots but sit in octets of different parity; row block rb must see ZERO in the octets of
+  //            the other set, so D[rb*8 + m][slot] sums column set rb only.
+  const int arow = (CS > 1 ? (nl & 7) : nl) % MT;  // activation row this lane feeds to its row block
+  int a_off = (arow * LK + kl) * KLS;
+  if constexpr (CS > 1) {
+    if ((nl >> 4) != ((nl >> 3) & 1)) a_off = MT * LK * KLS;  // the zero slot
+#pragma unroll
+    for (int i = lane; i < ZERO_DW; i += 64) my_act[MT * LK * KLS + i] = 0u;
+  }
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const uint32_t row_bytes = p.n * 4u;  // one packed row
@@ -328,7 +344,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
               for (int i = 0; i < BITS; ++i) acc[c][0] += __builtin_bit_cast(float, wc[c][i] & 0x3FFFFFFFu);
           }
         } else {
-          const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + (arow * LK + kl) * KLS + j * 16 + 4 * oct);
+          const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + a_off + j * 16 + 4 * oct);
           const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
           u32x4_t braw[CPL];
           static_for<4>([&](auto e_c) {
@@ -376,7 +392,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
       for (int r = 0; r < 4; ++r) {
         const int drow = 4 * (lane >> 4) + r;
         const int m = drow % RB;
-        if (drow / RB == ks && m < MT) s_red[((wv * RS + ks) * MT + m) * CN + snl * CPL + c] = acc[c][r];
+        if constexpr (CS > 1) {
+          if (m < MT) s_red[(wv * MT + m) * CN + ((drow / RB) * 16 + slot) * CPL + c] = acc[c][r];
+        } else {
+          if (drow / RB == ks && m < MT) s_red[((wv * RS + ks) * MT + m) * CN + snl * CPL + c] = acc[c][r];
+        }
       }
   }
   __syncthreads();
@@ -565,6 +585,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
       switch (variant) {
         case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
         case 106: return launch_la<BITS, UBMAX, 3, 16, 8, 0, lookahead_for<BITS>()>(p, stream);  // same launch, default unpack
+        case 107: return launch_m1<BITS, UBMAX, 4, 32, 16, true>(p, stream);   // 128-column tiles, nt
+        case 108: return launch_m1<BITS, UBMAX, 4, 16, 8, true>(p, stream);    // 64-column tiles, nt
+        case 109: return launch_m1<BITS, UBMAX, 3, 16, 8, false>(p, stream);   // 48-column tiles
         default: break;
       }
       if constexpr (BITS == 4) {  // launch-shape variants exist for the headline bit-width only
@@ -578,6 +601,12 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
           case 11: return launch_m1<BITS, 4, 2, 16, 8, true>(p, stream);
           case 12: return launch_m1<BITS, 4, 3, 16, 8, true>(p, stream);
           case 13: return launch_m1<BITS, 4, 4, 16, 8, true>(p, stream);
+          case 51: return launch_m1<BITS, 4, 4, 32, 16, false>(p, stream);  // 128-column tiles
+          case 52: return launch_m1<BITS, 4, 4, 32, 16, true>(p, stream);
+          case 53: return launch_m1<BITS, 4, 4, 32, 8, false>(p, stream);
+          case 54: return launch_m1<BITS, 4, 4, 32, 8, true>(p, stream);
+          case 55: return launch_m1<BITS, 4, 3, 32, 16, true>(p, stream);   // 96-column tiles
+          case 56: return launch_m1<BITS, 4, 2, 32, 16, true>(p, stream);   // 64-column tiles, 8-byte loads
           case 28: return launch_m1<BITS, 4, 2, 8, 8, false>(p, stream);
           case 39: return launch_m1<BITS, 2, 2, 8, 8, false>(p, stream);
           case 16: return launch_m1<BITS, 4, 3, 16, 8, false, 0>(p, stream);  // lookahead sweep
@@ -617,6 +646,16 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
     // 4096x4096 5.4 -> 4.5, 11008x4096 11.2 -> 8.5 (profiles/r01/sweep_k_heavy_shapes.txt).
     if (cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128 && p.m <= 8)
       return launch_rows<BITS, (UBMAX > 2 ? 2 : UBMAX), 2, 8, 8, false>(p, stream);
+    // Very wide layers (>= 200 tiles of 128 columns: 70B FFN up/gate, lm_head): 32 lanes side by side,
+    // 16 bytes each, so a wave-instruction reads 512 contiguous bytes of two packed rows (NL = 32: two
+    // column sets share the MFMA's column slots and are kept apart by zeroed A operands, see the
+    // kernel).  With nontemporal loads: 8192x28672 23.4 -> 21.9 us, 4096x32000 14.2 -> 13.1,
+    // 4096x28672 13.7 -> 12.5 (profiles/r01/sweep_wide_tiles.txt); plain loads gain nothing.  4- and
+    // 8-bit only: the 3/5/6/7-bit unpackers hold too many words per lane at 4 columns (5-bit 19.5 ->
+    // 26.9 us on 4096x32000), 2-bit ties.
+    if constexpr (BITS == 4 || BITS == 8) {
+      if (p.n >= 25600u && p.m <= 8 && kblocks / UBMAX >= 32) return launch_rows<BITS, UBMAX, 4, 32, 16, true>(p, stream);
+    }
     // 16 waves when there is at most one workgroup per CU and K fills them in one sweep; otherwise
     // 8-wave workgroups (several per CU, sweeping K): 8192x28672 26.2 -> 25.3 us, 28672x8192 28.1 -> 25.5
     const uint32_t tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
