@@ -375,3 +375,53 @@ def test_gemv_split_k_shapes(bits, cuda_device):
             assert_gemv_close(y1.cpu().numpy(), y_ref, "unsplit bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
     finally:
         raw.xbit_debug_set_gemv_split(0)
+
+
+def test_gemv_random_shapes(cuda_device):
+    """Seeded random shapes through every launch path the heuristics can take (whole-K tiles of
+    16/32/48/64/128 columns, 1/4/8/16 rows per pass, forced and automatic split-K, the generic
+    kernel for K % 8 != 0 or groups that are not a multiple of 32), ragged K and N included."""
+    import ctypes
+
+    import XbitOps
+    from xbitops_amd import _lib
+
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(2024)
+    try:
+        for case in range(48):
+            bits = int(rng.integers(2, 9))
+            g = int(rng.choice([16, 32, 64, 96, 128, 256]))
+            k = int(rng.integers(1, 40)) * g + int(rng.choice([0, 0, 8, 24, g // 2]))
+            if rng.random() < 0.15:
+                k += 4  # K % 8 != 0: generic kernel
+            n = int(rng.choice([2, 34, 96, 130, 256, 1000, 4096 + 6, 11008, 25600 + 62]))
+            m = int(rng.choice([1, 1, 1, 2, 4, 5, 8, 13, 16, 21]))
+            if k * n > 3e7:
+                k = max(g, (int(3e7 // n) // g) * g)
+            forced = int(rng.choice([0, 0, 0, 2, 3, 5]))
+            raw.xbit_debug_set_gemv_split(forced)
+            bias = int(rng.integers(0, 2))
+            p = synth.make_problem(k, n, bits, g, m=m, seed=7000 + case)
+            y = run_gemv(p, bias, cuda_device)
+            y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, bias, oracle.RNE)
+            assert_gemv_close(y, y_ref, "case %d bits=%d k=%d n=%d g=%d m=%d bias=%d split=%d" % (case, bits, k, n, g, m, bias, forced))
+    finally:
+        raw.xbit_debug_set_gemv_split(0)
+
+
+def test_dequant_random_shapes_bit_exact(cuda_device):
+    """Seeded random shapes through both dequant kernels (tile kernel: n % 8 == 0; generic kernel
+    otherwise), ragged K, every group size class: bit-exact against the oracle (RNE)."""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        bits = int(rng.integers(2, 9))
+        g = int(rng.choice([16, 32, 48, 64, 128, 256]))
+        k = int(rng.integers(1, 24)) * g + int(rng.choice([0, 0, 1, 7, 8, g // 2]))
+        n = int(rng.choice([2, 8, 34, 96, 136, 512, 1000, 4096 + 8]))
+        bias = int(rng.integers(0, 2))
+        p = synth.make_problem(k, n, bits, g, m=1, seed=8000 + case)
+        w = run_dequant(p, bias, cuda_device)
+        w_ref = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, bias, oracle.RNE)
+        assert np.array_equal(_bits(w), _bits(w_ref)), "case %d bits=%d k=%d n=%d g=%d bias=%d" % (case, bits, k, n, g, bias)
