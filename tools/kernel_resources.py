@@ -29,7 +29,7 @@ def main(pattern=""):
         for r, n in zip(rows, names):
             n = re.sub(r"^void ", "", n).split("(")[0]
             if pattern in n:
-                print("%-62s vgpr=%3s sgpr=%3s spill=%s scratch=%s lds=%s" % (n[:62], r[1], r[2], r[3], r[4], r[5]))
+                print("%-80s vgpr=%3s sgpr=%3s spill=%s scratch=%s lds=%s" % (n[:80], r[1], r[2], r[3], r[4], r[5]))
 
 
 if __name__ == "__main__":

@@ -1,29 +1,30 @@
 // xbit_gemv_mfma.h — the production A16Wx GEMV / skinny-GEMM kernel (M = 1..16 per pass) for gfx950.
 //
-// Same decomposition as xbit_gemv.hip (a workgroup owns a column tile over all of K; lanes own
-// whole 32-k blocks; all packed-weight loads of a batch are issued before any is consumed; the
-// activation slice is staged per wave in LDS in the unpacker's pair order; W is rebuilt bit-exactly
-// in packed fp16), but the multiply-accumulate runs on the matrix pipe:
+// A workgroup owns a column tile over all of K (or one K range of it: split-K); lanes own whole
+// 32-k blocks of CPL adjacent columns; the packed rows of a lane are loaded a few rows ahead of the
+// step that consumes them (LA); the activation slice of a wave is staged in LDS in the unpacker's
+// pair order; W is rebuilt bit-exactly in packed fp16 (xbit_device.h) and multiplied on the matrix
+// pipe:
 //
 //   v_mfma_f32_16x16x32_f16:  D[16 x 16] += A[16 x 32] * B[32 x 16],  fp32 accumulate
 //     lane l supplies  B[k = 8*(l>>4) + j][col = l&15]  and  A[row = l&15][k = 8*(l>>4) + j], j < 8.
 //
 // Why a matrix instruction in a bandwidth-bound GEMV: measured on MI355X (tools/microbench/
-// valu_rates.hip, profiles/) every VALU op this kernel needs — v_and_or_b32, v_pk_add_f16,
-// v_pk_fma_f16 and also v_dot2c_f32_f16 — retires one wave-instruction per ~3.5 cycles per SIMD at
-// best (7 with one wave per SIMD).  With the dot product on the VALU (xbit_gemv.hip: 4.3 ops per
-// pair of weights) the unpack+MAC stream needs 2-3x the time HBM needs to deliver the weights.
-// Moving the MACs to the otherwise idle matrix pipe removes a quarter of the VALU stream, removes
-// the cross-lane shuffle reduction (the MFMA sums the four k-lane groups), and makes M = 2..16
-// rows cost the same as M = 1.  Nothing is reshaped: the "k" of the MFMA is simply 4 lane groups x
-// 8 consecutive fields of the k-block each lane already owns.
+// valu_rates.hip, profiles/) the packed-fp16 ops and v_dot2c_f32_f16 retire one wave-instruction
+// per ~3.5 cycles per SIMD at best.  With the dot product on the VALU (xbit_gemv.hip: 4.3 ops per
+// pair of weights) the kernel was VALU-bound at 8.8-9.3 us on the 23 MB metric shape.  Moving the
+// MACs to the otherwise idle matrix pipe removes them from the VALU stream, removes the cross-lane
+// shuffle reduction (the MFMA sums the four k-lane groups), and makes M = 2..16 rows cost about the
+// same as M = 1.  Nothing is reshaped: the "k" of the MFMA is simply 4 lane groups x 8 consecutive
+// fields of the k-block each lane already owns.
 //
-// Lane map (wave64): kq = lane >> 4 picks the k-batch (UB k-blocks) of this lane, nc = lane & 15 the
-// column group; a lane loads CPL adjacent columns (8 or 16 bytes) of each packed row of its
-// k-blocks.  MFMA step (block j, octet i, column c): B fragment = fields 8i..8i+7 (pair order) of
-// block j, column c, from every lane; A fragment = the matching 8 activations of row (nc % MT),
-// read from LDS as one broadcast ds_read_b128.  Output element: D[row][nc] of accumulator c is
-// y[m0 + row][tile*CN + nc*CPL + c].
+// Lane map (wave64, NL = 16): kl = lane >> 4 picks the k-batch (UB k-blocks) of this lane, nl =
+// lane & 15 the column group; a lane loads CPL adjacent columns (8, 12 or 16 bytes) of each packed row
+// of its k-blocks.  MFMA step (block j, octet i, column c): B fragment = fields 8i..8i+7 (pair
+// order) of block j, column c, from every lane; A fragment = the matching 8 activations of row
+// (nl % MT), read from LDS as one ds_read_b128.  Output element: D[row][nl] of accumulator c is
+// y[m0 + row][tile*CN + nl*CPL + c].  NL = 8 and NL = 32 re-map lanes to narrower / wider tiles (see
+// the kernel).
 #pragma once
 
 #include "xbit_device.h"
@@ -83,10 +84,12 @@ struct RowLoad {
 //   BITS  weight width 2..8          UB   k-blocks per lane and sweep (UB*BITS row loads in flight)
 //   CPL   adjacent columns per lane: 2, 3 or 4 (8/12/16-byte loads; tile = NL*CPL columns).  Picked
 //         by the launcher so that the number of tiles sits just under a multiple of the CU count.
-//   NL    lanes side by side along N (16 or 8).  The MFMA tile has 16 column slots (lane & 15):
+//   NL    lanes side by side along N (8, 16 or 32).  The MFMA tile has 16 column slots (lane & 15):
 //         with NL = 16 they are 16 column groups; with NL = 8 they are 8 column groups x 2 k-slots,
 //         kept apart by feeding their activations to row blocks 0-7 and 8-15 of the A operand:
-//         D[ks*8 + m][ks*8 + nl] is the sum over k-slot ks, the off-diagonal quadrants are don't-care.
+//         D[ks*8 + m][ks*8 + nl] is the sum over k-slot ks, the off-diagonal quadrants are don't-care;
+//         with NL = 32 two column sets share the slots in k-octets of different parity and each row
+//         block carries zeros in the other set's octets (512 contiguous bytes per row and instruction).
 //   NW    waves per workgroup        MT   activation rows per pass (<= NL)
 //   NT    nontemporal weight loads   GUARD  false when the shape needs no edge handling at all
 //   ABLATE (measurement builds only): 1 = no weight loads (registers stand in), 2 = no
