@@ -36,9 +36,9 @@
  * (gemv_w4a16_pt.cu:152-155,168-172; unpack_weight_2_to_7.cu:436-440).  These functions never
  * abort: they return 0 on success, a negative XBIT_ERR_* for a rejected argument, or a positive
  * hipError_t if the HIP runtime refused the launch.  Launches are asynchronous on `hip_stream`.
- * The library is safe to call from several host threads.  Its only state is a 4 MiB scratch buffer
- * per (device, stream), allocated the first time a GEMV with few output columns and K >= 14336 is
- * split over K on that stream (never inside a stream capture); results do not depend on it.
+ * The library is safe to call from several host threads.  Its only state is a 2 MiB scratch buffer
+ * per (device, stream), allocated the first time a GEMV with few output columns (N <= 4608) and
+ * K >= 8192 is split over K on that stream (never inside a stream capture).
  */
 #ifndef XBITOPS_HIP_H_
 #define XBITOPS_HIP_H_

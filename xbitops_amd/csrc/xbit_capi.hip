@@ -37,8 +37,7 @@ static std::atomic<int> g_gemv_split{0};
 int gemv_split_override() { return g_gemv_split.load(std::memory_order_relaxed); }
 
 namespace {
-constexpr size_t kPartialFloats = (size_t)1 << 20;  // 4 MiB of fp32 partial sums per stream
-constexpr size_t kCounterSlots = (size_t)1 << 14;
+constexpr size_t kAccSlots = (size_t)1 << 18;  // 2 MiB of 64-bit accumulators per stream
 std::mutex g_ws_mutex;
 std::map<std::pair<int, hipStream_t>, GemvWorkspace> g_ws;  // never freed: lives as long as the process
 }  // namespace
@@ -53,7 +52,7 @@ bool gemv_workspace(hipStream_t stream, GemvWorkspace* out) {
   auto it = g_ws.find({dev, stream});
   if (it != g_ws.end()) {
     *out = it->second;
-    return out->partial != nullptr;
+    return out->acc != nullptr;
   }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
@@ -61,17 +60,14 @@ bool gemv_workspace(hipStream_t stream, GemvWorkspace* out) {
     return false;  // not remembered: a later call outside the capture allocates
   }
   GemvWorkspace ws;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&ws.partial), kPartialFloats * sizeof(float)) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&ws.counters), kCounterSlots * sizeof(uint32_t)) == hipSuccess &&
-            hipMemsetAsync(ws.counters, 0, kCounterSlots * sizeof(uint32_t), stream) == hipSuccess;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&ws.acc), kAccSlots * sizeof(unsigned long long)) == hipSuccess &&
+            hipMemsetAsync(ws.acc, 0, kAccSlots * sizeof(unsigned long long), stream) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
-    if (ws.partial) (void)hipFree(ws.partial);
-    if (ws.counters) (void)hipFree(ws.counters);
+    if (ws.acc) (void)hipFree(ws.acc);
     ws = GemvWorkspace{};
   } else {
-    ws.partial_floats = kPartialFloats;
-    ws.counter_slots = kCounterSlots;
+    ws.slots = kAccSlots;
   }
   g_ws[{dev, stream}] = ws;  // a failed allocation is remembered too: no retry storm
   *out = ws;
@@ -163,8 +159,7 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
   p.trace = xbit::gemv_trace_buffer();
   p.splits = 1;
   p.bps = 0;
-  p.partial = nullptr;
-  p.counters = nullptr;
+  p.acc = nullptr;
   return xbit::launch_gemv(p, bits, static_cast<hipStream_t>(hip_stream));
 }
 

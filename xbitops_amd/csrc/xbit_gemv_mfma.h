@@ -103,9 +103,9 @@ struct RowLoad {
 //        step s the loads needed by steps <= s + LA are issued, so a wave computes while its later
 //        rows are in flight and never holds more than LA + 1 queue slots.
 //   SPLIT  split-K: workgroup (tile, split) sums k-batches [split*bps, (split+1)*bps) only; the
-//        partial sums meet in a workspace and the last workgroup of a tile to arrive adds them in
-//        split order (so the result does not depend on the arrival order) and writes the output.
-//        For few column tiles and long K (down-projections), where whole-K tiles leave CUs idle.
+//        partial sums meet in per-element 64-bit fixed-point accumulators (one returning atomic
+//        per element and workgroup, see the epilogue).  For few column tiles and long K
+//        (down-projections), where whole-K tiles leave CUs idle.
 template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) {
   static_assert(!SPLIT || GUARD, "split-K launches use the guarded build");
@@ -409,34 +409,33 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < NW * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
+    const uint32_t n_out = tile * CN + c, row = m0 + m;
+    const bool valid = !GUARD || (n_out < p.n && row < p.m);
     if constexpr (SPLIT) {
-      // device-scope relaxed atomic store = write-through store (sc1): visible to every XCD once
-      // vmcnt retires it, without a release fence (which would write back the whole L2)
-      __hip_atomic_store(p.partial + (((size_t)blockIdx.y * p.tiles + tile) * p.splits + split) * (size_t)(MT * CN) + e, sum,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const uint32_t n_out = tile * CN + c, row = m0 + m;
-      if (!GUARD || (n_out < p.n && row < p.m)) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
-    }
-  }
-  if constexpr (SPLIT) {
-    __shared__ uint32_t s_last;
-    uint32_t* const ticket = p.counters + (size_t)blockIdx.y * p.tiles + tile;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have reached device scope
-    __syncthreads();                                   // ... and so have every wave's
-    if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == p.splits) ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-      const float* part = p.partial + ((size_t)blockIdx.y * p.tiles + tile) * p.splits * (size_t)(MT * CN);
-      for (int e = tid; e < MT * CN; e += 64 * NW) {
-        const int m = e / CN, c = e % CN;
-        float sum = 0.f;
-        for (uint32_t sp = 0; sp < p.splits; ++sp)
-          sum += __hip_atomic_load(part + (size_t)sp * (MT * CN) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t n_out = tile * CN + c, row = m0 + m;
-        if (n_out < p.n && row < p.m) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
+      // Cross-workgroup reduction in ONE trip to the device coherence point: the partial sum is
+      // added to the element's 64-bit accumulator as a fixed-point integer (2^-28 units, biased
+      // to stay positive) by a returning atomic whose upper bits count the arrivals.  Integer
+      // addition is associative, so the total does not depend on the arrival order; 2^-28 is below
+      // half the smallest fp16 spacing.  The thread that completes the count converts and stores,
+      // then clears the slot for the next launch.  Layout: bits 0-55 sum of (v + 2^51), 56-59
+      // arrivals, 60-63 arrivals whose partial sum was not finite / out of range (-> NaN).
+      if (valid) {
+        unsigned long long* slot = p.acc + ((size_t)blockIdx.y * p.tiles + tile) * (size_t)(MT * CN) + e;
+        const bool fin = __builtin_fabsf(sum) < 8388608.0f;  // 2^23; false for NaN / Inf too
+        const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;  // |v| < 2^51
+        const unsigned long long add = (unsigned long long)(v + (1ll << 51)) + (1ull << 56) + (fin ? 0ull : (1ull << 60));
+        const unsigned long long old = __hip_atomic_fetch_add(slot, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((old >> 56) & 15ull) + 1ull == p.splits) {
+          const unsigned long long tot = old + add;
+          const long long fixed = (long long)(tot & ((1ull << 56) - 1ull)) - (long long)p.splits * (1ll << 51);
+          float y = (float)fixed * (1.0f / 268435456.0f);
+          if (tot >> 60) y = __builtin_nanf("");
+          p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)y);
+          __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
-      if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    } else {
+      if (valid) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
     }
   }
   if constexpr (ABLATE & 8) {
@@ -476,31 +475,34 @@ int launch_m1(const GemvParams& p, hipStream_t stream) {
 }
 
 // split-K launch (see SPLIT): grid.x = tiles * splits
-template <int BITS, int UB, int CPL, int NW, int MT>
+template <int BITS, int UB, int CPL, int NL, int NW, int MT>
 int launch_split(GemvParams p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws) {
-  constexpr int CN = 16 * CPL;
+  constexpr int CN = NL * CPL;
   p.tiles = (p.n + CN - 1) / CN;
   p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
   p.splits = splits;
   p.bps = (p.batches + splits - 1) / splits;
-  p.partial = ws.partial;
-  p.counters = ws.counters;
+  p.acc = ws.acc;
   dim3 grid(p.tiles * splits, (p.m + MT - 1) / MT), block(64 * NW);
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, MT, false, true, 0, lookahead_for<BITS>(), true>, grid, block, stream, p);
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, false, true, 0, lookahead_for<BITS>(), true>, grid, block, stream, p);
 }
 
-template <int BITS, int UB, int CPL, int NW>
+template <int BITS, int UB, int CPL, int NL, int NW>
 int launch_split_rows(const GemvParams& p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws) {
-  if (p.m == 1) return launch_split<BITS, UB, CPL, NW, 1>(p, stream, splits, ws);
-  return launch_split<BITS, UB, CPL, NW, 4>(p, stream, splits, ws);
+  if (p.m == 1) return launch_split<BITS, UB, CPL, NL, NW, 1>(p, stream, splits, ws);
+  return launch_split<BITS, UB, CPL, NL, NW, 4>(p, stream, splits, ws);
 }
 
-// Split-K plan.  Measured on MI355X (profiles/r01/sweep_split_k.txt): the reduction tail (partial
-// store -> ticket -> partial loads, three trips to the device coherence point) costs ~3 us, so
-// splitting pays only when N is small (<= 80 tiles of 64 columns) AND K is long (>= 14336):
-// 28672x4096 18.5 -> 15.5 us, 28672x2048 17.0 -> 11.0, 32768x1024 17.6 -> 9.5; it loses on
-// 11008x4096 and on everything with N >= 8192.  tiles x splits ~ 256 workgroups of 8 waves; 64-column
-// tiles unless that needs more than 8 splits.  splits == 0: do not split.
+// Split-K plan.  Measured on MI355X (profiles/r01/sweep_split_k_v2.txt): with the one-atomic reduction
+// the tail costs ~1.5 us (the earlier store -> ticket -> load protocol cost ~3 us), so splitting pays
+// when N is small (<= 144 tiles of 32 columns) and K >= 8192: 11008x4096 8.6 -> 7.9 us, 14336x4096
+// 10.4 -> 8.7, 28672x4096 17.6 -> 13.9, 8192x3584 6.8 -> 6.1; not at K = 4096 (4096x4096 4.5 -> 5.7)
+// nor at N >= 8192 (8192x8192 9.3 -> 9.5).  Choice of tile width and split count: fill ~256
+// workgroups of 8 waves with k-ranges that fill whole sweeps of 32 batches; score = wave
+// utilisation x sqrt(CU fill), 32-column tiles discounted by 0.85 against 64-column ones (256-byte row
+// segments): at equal split counts the wide tiles win whenever they still give >= ~190 workgroups
+// (11008x4096 s3: 7.9 vs 8.5 us), the narrow ones when they do not (8192x4096 s2: 6.3 vs 7.5).
+// splits == 0: do not split.
 struct SplitPlan {
   int cpl = 0;
   uint32_t splits = 0;
@@ -509,22 +511,38 @@ inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits) {
   SplitPlan plan;
   if (p.m > 4 || forced_splits == 1) return plan;
   const uint32_t kblocks = (p.k + 31) / 32, batches = (kblocks + ub - 1) / ub;
-  const uint32_t tiles64 = (p.n + 63) / 64, tiles32 = (p.n + 31) / 32;
-  if (forced_splits <= 0 && !(tiles64 <= 80 && kblocks >= 448)) return plan;
-  plan.cpl = tiles64 * 8 >= 200 ? 4 : 2;
-  const uint32_t tiles = plan.cpl == 4 ? tiles64 : tiles32;
-  uint32_t splits = forced_splits > 0 ? (uint32_t)forced_splits : (256u + tiles / 2) / tiles;
-  if (splits > 8u && forced_splits <= 0) splits = 8u;
-  if (splits > batches / 8u) splits = batches / 8u;  // at least 8 batches per split
-  if (splits > 64u) splits = 64u;
-  plan.splits = splits >= 2u ? splits : 0u;
+  const uint32_t tiles32 = (p.n + 31) / 32;
+  if (forced_splits > 0) {
+    plan.cpl = 4;
+    plan.splits = (uint32_t)forced_splits < 15u ? (uint32_t)forced_splits : 15u;
+    if (plan.splits > batches / 8u) plan.splits = batches / 8u;
+    if (plan.splits < 2u) plan.splits = 0;
+    return plan;
+  }
+  if (tiles32 > 144u || kblocks < 256u) return plan;
+  double best = 0.0;
+  for (int cpl = 4; cpl >= 2; cpl -= 2) {
+    const uint32_t tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
+    for (uint32_t sp = 2; sp <= 15u; ++sp) {
+      const uint32_t bps = (batches + sp - 1) / sp;
+      if (bps < 16u) break;
+      const uint32_t sweeps = (bps + 31u) / 32u, wgs = tiles * sp;
+      const double fill = wgs < 256u ? wgs / 256.0 : 1.0;
+      const double score = (double)bps / (32.0 * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85);
+      if (score > best + 1e-9) {
+        best = score;
+        plan.cpl = cpl;
+        plan.splits = sp;
+      }
+    }
+  }
   return plan;
 }
 
 template <int BITS, int UB>
 int launch_plan(const GemvParams& p, hipStream_t stream, const SplitPlan& plan, const GemvWorkspace& ws) {
-  if (plan.cpl == 4) return launch_split_rows<BITS, UB, 4, 8>(p, stream, plan.splits, ws);
-  return launch_split_rows<BITS, UB, 2, 8>(p, stream, plan.splits, ws);
+  if (plan.cpl == 4) return launch_split_rows<BITS, UB, 4, 16, 8>(p, stream, plan.splits, ws);
+  return launch_split_rows<BITS, UB, 2, 16, 8>(p, stream, plan.splits, ws);
 }
 
 // measurement-only launches (M = 1, plain loads): ablated or stamped builds, see ABLATE
@@ -636,11 +654,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
       }
       if (plan.splits >= 2) {
         const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
-        const size_t floats = (size_t)mblocks * tiles * plan.splits * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
+        const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
         GemvWorkspace ws;
-        if (floats <= ((size_t)1 << 20) && (size_t)mblocks * tiles <= ((size_t)1 << 14) && gemv_workspace(stream, &ws) &&
-            floats <= ws.partial_floats && (size_t)mblocks * tiles <= ws.counter_slots)
-          return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
+        if (slots <= ((size_t)1 << 18) && gemv_workspace(stream, &ws) && slots <= ws.slots) return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
       }
     }
     // Few tiles (e.g. the 8192x3584 shard of a 70B FFN on 8 GPUs: 112 tiles of 32 columns; 4096x4096):

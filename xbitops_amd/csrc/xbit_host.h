@@ -30,20 +30,18 @@ struct GemvParams {
   uint32_t batches;  // k-batches of UB k-blocks
   uint64_t* trace;   // measurement builds only: per-wave s_memrealtime stamps (else nullptr)
   // split-K launches only (few column tiles, long K): K is cut into `splits` ranges of `bps`
-  // batches, one workgroup each; partial sums meet in `partial`, the last workgroup to arrive
-  // (ticket in `counters`) adds them in split order and writes the fp16 result.
+  // batches, one workgroup each.  Every output element has a 64-bit accumulator in `acc`; each
+  // workgroup adds its partial sum there as a fixed-point integer with ONE returning atomic that
+  // also counts arrivals, and the thread that sees the last arrival writes the fp16 result.
   uint32_t splits, bps;
-  float* partial;      // [grid.y][tiles][splits][MT * CN] fp32
-  uint32_t* counters;  // [grid.y][tiles], zero between launches (the last arriver resets its ticket)
+  unsigned long long* acc;  // [grid.y][tiles][MT * CN], zero between launches (the last arriver resets its slot)
 };
 
 // Per-(device, stream) scratch for split-K launches: launches on one stream run in order, so they
 // can share it; different streams get their own.  Allocated on first use and kept.
 struct GemvWorkspace {
-  float* partial = nullptr;
-  uint32_t* counters = nullptr;
-  size_t partial_floats = 0;
-  size_t counter_slots = 0;
+  unsigned long long* acc = nullptr;
+  size_t slots = 0;
 };
 // false: no workspace for this stream (allocation failed, or the first use would fall inside a
 // stream capture, where allocation is not allowed) - the caller then launches without split-K.
