@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   constexpr int RB = 16 / (RS * CS);         // rows per row block of the A tile
   static_assert(MT == 1 || MT == 2 || MT == 4 || MT == 8 || MT == 16, "rows per pass");
   static_assert(MT <= RB, "rows per pass exceed the row block");
-  constexpr int T = LK * NW;             // k-batches per workgroup sweep
+  // NW is the LARGEST workgroup this build is launched with (it sizes LDS and the register budget);
+  // the launcher picks the actual wave count so that K fills whole sweeps (K = 5120: 10 waves)
   constexpr int CN = NL * CPL;           // columns per workgroup
   constexpr int KLS = UB * 16 + 4;       // dwords per (row, k-slot) activation slot (+4: bank spread)
   constexpr int ZERO_DW = CS > 1 ? KLS : 0;         // NL = 32: an all-zero slot for the lanes that feed the other column set
@@ -141,6 +142,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   float* const s_red = reinterpret_cast<float*>(s_lds + (ALIAS ? 0 : NW * ACT_DW));
 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / NL, nl = lane % NL;
+  const int nwaves = (int)(blockDim.x >> 6);   // <= NW
+  const uint32_t T = (uint32_t)(LK * nwaves);  // k-batches per workgroup sweep
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
   const uint32_t tile = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);
   const uint32_t b_begin = SPLIT ? split * p.bps : 0u;
@@ -404,11 +407,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   }
   __syncthreads();
   if constexpr (ABLATE & 8) stamp[4] = __builtin_amdgcn_s_memrealtime();  // past the workgroup barrier
-  for (int e = tid; e < MT * CN; e += 64 * NW) {
+  for (int e = tid; e < MT * CN; e += 64 * nwaves) {
     const int m = e / CN, c = e % CN;
     float sum = 0.f;
-#pragma unroll
-    for (int v = 0; v < NW * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
+    for (int v = 0; v < nwaves * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
     const uint32_t n_out = tile * CN + c, row = m0 + m;
     const bool valid = !GUARD || (n_out < p.n && row < p.m);
     if constexpr (SPLIT) {
@@ -456,13 +458,23 @@ constexpr int lookahead_for() {
   return (BITS >= 5 && BITS <= 7) ? 6 : kLookahead;
 }
 
+// Waves per workgroup for `batches` k-batches at `lk` k-slots per wave: one sweep if `cap` waves
+// cover K, otherwise the fewest equal sweeps - so K = 5120 (40 batches) runs 10 waves x 1 sweep or
+// 5 x 2 instead of 8 waves with a second sweep that is three-quarters idle.  At least 4 waves.
+inline uint32_t sweep_waves(uint32_t batches, uint32_t lk, uint32_t cap) {
+  const uint32_t w = (batches + lk - 1) / lk;
+  if (w <= cap) return w < 4u ? 4u : w;
+  const uint32_t sweeps = (w + cap - 1) / cap;
+  return (w + sweeps - 1) / sweeps;
+}
+
 template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, int LA = kLookahead>
-int launch_one(GemvParams p, hipStream_t stream) {
+int launch_one(GemvParams p, hipStream_t stream, uint32_t waves = NW) {
   constexpr int CN = NL * CPL;
   p.tiles = (p.n + CN - 1) / CN;
   const uint32_t kblocks = (p.k + 31) / 32;
   p.batches = (kblocks + UB - 1) / UB;
-  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * NW);
+  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * (waves < (uint32_t)NW ? waves : (uint32_t)NW));
   // One build per launch shape, edge handling always on: the unguarded build measured the same
   // (6.7 vs 6.8 us on 4096x11008) and doubled the number of kernels to compile.
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, NT, true, 0, LA>, grid, block, stream, p);
@@ -476,21 +488,23 @@ int launch_m1(const GemvParams& p, hipStream_t stream) {
 
 // split-K launch (see SPLIT): grid.x = tiles * splits
 template <int BITS, int UB, int CPL, int NL, int NW, int MT>
-int launch_split(GemvParams p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws) {
+int launch_split(GemvParams p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws, uint32_t waves) {
   constexpr int CN = NL * CPL;
   p.tiles = (p.n + CN - 1) / CN;
   p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
   p.splits = splits;
   p.bps = (p.batches + splits - 1) / splits;
   p.acc = ws.acc;
-  dim3 grid(p.tiles * splits, (p.m + MT - 1) / MT), block(64 * NW);
+  dim3 grid(p.tiles * splits, (p.m + MT - 1) / MT), block(64 * (waves < (uint32_t)NW ? waves : (uint32_t)NW));
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, MT, false, true, 0, lookahead_for<BITS>(), true>, grid, block, stream, p);
 }
 
 template <int BITS, int UB, int CPL, int NL, int NW>
 int launch_split_rows(const GemvParams& p, hipStream_t stream, uint32_t splits, const GemvWorkspace& ws) {
-  if (p.m == 1) return launch_split<BITS, UB, CPL, NL, NW, 1>(p, stream, splits, ws);
-  return launch_split<BITS, UB, CPL, NL, NW, 4>(p, stream, splits, ws);
+  const uint32_t batches = ((p.k + 31) / 32 + UB - 1) / UB, bps = (batches + splits - 1) / splits;
+  const uint32_t waves = sweep_waves(bps, 64 / NL, NW);
+  if (p.m == 1) return launch_split<BITS, UB, CPL, NL, NW, 1>(p, stream, splits, ws, waves);
+  return launch_split<BITS, UB, CPL, NL, NW, 4>(p, stream, splits, ws, waves);
 }
 
 // Split-K plan.  Measured on MI355X (profiles/r01/sweep_split_k_v2.txt): with the one-atomic reduction
@@ -498,7 +512,7 @@ int launch_split_rows(const GemvParams& p, hipStream_t stream, uint32_t splits, 
 // when N is small (<= 144 tiles of 32 columns) and K >= 8192: 11008x4096 8.6 -> 7.9 us, 14336x4096
 // 10.4 -> 8.7, 28672x4096 17.6 -> 13.9, 8192x3584 6.8 -> 6.1; not at K = 4096 (4096x4096 4.5 -> 5.7)
 // nor at N >= 8192 (8192x8192 9.3 -> 9.5).  Choice of tile width and split count: fill ~256
-// workgroups of 8 waves with k-ranges that fill whole sweeps of 32 batches; score = wave
+// workgroups of 4-8 waves with k-ranges that fill whole sweeps (sweep_waves); score = wave
 // utilisation x sqrt(CU fill), 32-column tiles discounted by 0.85 against 64-column ones (256-byte row
 // segments): at equal split counts the wide tiles win whenever they still give >= ~190 workgroups
 // (11008x4096 s3: 7.9 vs 8.5 us), the narrow ones when they do not (8192x4096 s2: 6.3 vs 7.5).
@@ -519,16 +533,16 @@ inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits) {
     if (plan.splits < 2u) plan.splits = 0;
     return plan;
   }
-  if (tiles32 > 144u || kblocks < 256u) return plan;
+  if (kblocks < 256u || tiles32 > 176u || (tiles32 > 144u && kblocks < 384u)) return plan;  // 8192x5120 loses (7.7 -> 8.3 us), 13824x5120 gains (13.0 -> 12.4)
   double best = 0.0;
   for (int cpl = 4; cpl >= 2; cpl -= 2) {
     const uint32_t tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
     for (uint32_t sp = 2; sp <= 15u; ++sp) {
       const uint32_t bps = (batches + sp - 1) / sp;
       if (bps < 16u) break;
-      const uint32_t sweeps = (bps + 31u) / 32u, wgs = tiles * sp;
+      const uint32_t waves = sweep_waves(bps, 4, 8), sweeps = (bps + 4u * waves - 1) / (4u * waves), wgs = tiles * sp;
       const double fill = wgs < 256u ? wgs / 256.0 : 1.0;
-      const double score = (double)bps / (32.0 * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85);
+      const double score = (double)bps / (4.0 * waves * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85);
       if (score > best + 1e-9) {
         best = score;
         plan.cpl = cpl;
@@ -555,15 +569,27 @@ int launch_la(GemvParams p, hipStream_t stream) {
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
 }
 
-// rows per pass: 1, 4, 8 or 16 (fewer staged rows = less LDS traffic); NL = 8 tiles take <= 8 rows
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int LA = lookahead_for<BITS>()>
+// rows per pass: 1, 4, 8 or 16 (fewer staged rows = less LDS traffic); NL = 8 / 32 tiles take <= 8 rows.
+// Workgroup size: up to 16 waves when there is at most one workgroup per CU (<= 240 tiles), up to 8
+// otherwise (several 8-wave workgroups per CU sweeping K measured better: 8192x28672 26.2 -> 25.3 us,
+// 8192x8192 9.8 -> 9.2); within that cap, as many waves as fill whole sweeps (sweep_waves).
+template <int BITS, int UB, int CPL, int NL, bool NT, int LA = lookahead_for<BITS>()>
 int launch_rows(const GemvParams& p, hipStream_t stream) {
-  if (p.m == 1) return launch_one<BITS, UB, CPL, NL, NW, 1, NT, LA>(p, stream);
-  if (p.m <= 4) return launch_one<BITS, UB, CPL, NL, NW, 4, NT, LA>(p, stream);
-  // 8-16 rows: the staged activation tile is 8-16x larger (LDS: NW*MT*4*(UB*16+4)*4 bytes, 139 KB
-  // at UB = 4, NW = 8, MT = 16).  Measured on 4096x11008 w4 M=16: NW = 8 is 9.0-9.3 us, NW = 4 11.0 us.
-  if (p.m <= 8) return launch_one<BITS, UB, CPL, NL, 8, 8, NT, LA>(p, stream);
-  return launch_one<BITS, UB, CPL, 16, 8, 16, NT, LA>(p, stream);
+  constexpr uint32_t LK = 64 / NL, CN = NL * CPL;
+  const uint32_t batches = ((p.k + 31) / 32 + UB - 1) / UB, tiles = (p.n + CN - 1) / CN;
+  if (p.m <= 4) {
+    const uint32_t waves = sweep_waves(batches, LK, tiles <= 240u ? 16u : 8u);
+    if (waves <= 8u) {
+      if (p.m == 1) return launch_one<BITS, UB, CPL, NL, 8, 1, NT, LA>(p, stream, waves);
+      return launch_one<BITS, UB, CPL, NL, 8, 4, NT, LA>(p, stream, waves);
+    }
+    if (p.m == 1) return launch_one<BITS, UB, CPL, NL, 16, 1, NT, LA>(p, stream, waves);
+    return launch_one<BITS, UB, CPL, NL, 16, 4, NT, LA>(p, stream, waves);
+  }
+  // 8-16 rows: the staged activation tile is 8-16x larger (139 KB of LDS at UB = 4, 8 waves, 16 rows).
+  // Measured on 4096x11008 w4 M=16: 8 waves 9.0-9.3 us, 4 waves 11.0 us.
+  if (p.m <= 8) return launch_one<BITS, UB, CPL, NL, 8, 8, NT, LA>(p, stream, sweep_waves(batches, LK, 8));
+  return launch_one<BITS, UB, CPL, 16, 8, 16, NT, LA>(p, stream, sweep_waves(batches, 4, 8));
 }
 
 template <int BITS>
@@ -587,12 +613,12 @@ inline int pick_cpl(uint32_t n) {
   return best;
 }
 
-template <int BITS, int UB, int NW, bool NT = false>
+template <int BITS, int UB, bool NT = false>
 int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl) {
   switch (cpl) {
-    case 4: return launch_rows<BITS, UB, 4, 16, NW, NT>(p, stream);
-    case 3: return launch_rows<BITS, UB, 3, 16, NW, NT>(p, stream);
-    default: return launch_rows<BITS, UB, 2, 16, NW, NT>(p, stream);
+    case 4: return launch_rows<BITS, UB, 4, 16, NT>(p, stream);
+    case 3: return launch_rows<BITS, UB, 3, 16, NT>(p, stream);
+    default: return launch_rows<BITS, UB, 2, 16, NT>(p, stream);
   }
 }
 
@@ -664,7 +690,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
     // twice as many CUs get work, with 2 k-blocks per lane and sweep.  Measured: 8192x3584 7.6 -> 6.8 us,
     // 4096x4096 5.4 -> 4.5, 11008x4096 11.2 -> 8.5 (profiles/r01/sweep_k_heavy_shapes.txt).
     if (cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128 && p.m <= 8)
-      return launch_rows<BITS, (UBMAX > 2 ? 2 : UBMAX), 2, 8, 8, false>(p, stream);
+      return launch_rows<BITS, (UBMAX > 2 ? 2 : UBMAX), 2, 8, false>(p, stream);
     // Very wide layers (>= 200 tiles of 128 columns: 70B FFN up/gate, lm_head): 32 lanes side by side,
     // 16 bytes each, so a wave-instruction reads 512 contiguous bytes of two packed rows (NL = 32: two
     // column sets share the MFMA's column slots and are kept apart by zeroed A operands, see the
@@ -673,23 +699,19 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
     // 8-bit only: the 3/5/6/7-bit unpackers hold too many words per lane at 4 columns (5-bit 19.5 ->
     // 26.9 us on 4096x32000), 2-bit ties.
     if constexpr (BITS == 4 || BITS == 8) {
-      if (p.n >= 25600u && p.m <= 8 && kblocks / UBMAX >= 32) return launch_rows<BITS, UBMAX, 4, 32, 16, true>(p, stream);
+      if (p.n >= 25600u && p.m <= 8 && kblocks / UBMAX >= 32) return launch_rows<BITS, UBMAX, 4, 32, true>(p, stream);
     }
-    // 16 waves when there is at most one workgroup per CU and K fills them in one sweep; otherwise
-    // 8-wave workgroups (several per CU, sweeping K): 8192x28672 26.2 -> 25.3 us, 28672x8192 28.1 -> 25.5
-    const uint32_t tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
-    if (kblocks / UBMAX >= 64 && tiles <= 240) return launch_cpl<BITS, UBMAX, 16>(p, stream, cpl);
     // Weight loads are plain by default: equal to nontemporal when the weights come from HBM and ~8 %
     // faster when they are still in the Infinity Cache (4096x11008).  Very large, wide layers cannot
     // stay cached anyway and stream ~9 % faster nontemporal (8192x28672: 25.8 -> 23.4 us); long
     // narrow ones (28672x8192) show no difference.  (profiles/r01/sweep_nt_large_shapes.txt)
-    if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) return launch_cpl<BITS, UBMAX, 8, true>(p, stream, cpl);
-    return launch_cpl<BITS, UBMAX, 8>(p, stream, cpl);
+    if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) return launch_cpl<BITS, UBMAX, true>(p, stream, cpl);
+    return launch_cpl<BITS, UBMAX>(p, stream, cpl);
   }
   if constexpr (UBMAX > 2) {
-    if (p.groupsize % 64u == 0) return launch_cpl<BITS, 2, 8>(p, stream, cpl);
+    if (p.groupsize % 64u == 0) return launch_cpl<BITS, 2>(p, stream, cpl);
   }
-  return launch_cpl<BITS, 1, 8>(p, stream, cpl);
+  return launch_cpl<BITS, 1>(p, stream, cpl);
 }
 
 }  // namespace
