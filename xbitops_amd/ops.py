@@ -79,8 +79,36 @@ def add_zero_bias_check(v: int) -> int:
     return v
 
 
-def _stream_ptr(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a Stream object
+
+
+def _stream_ptr(index: int) -> int:
+    """Raw hipStream_t of torch's current stream on device ``index``."""
+    if _raw_stream is not None:
+        return _raw_stream(index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+class _on_device:
+    """``with _on_device(i):`` makes device ``i`` current and restores the caller's device afterwards;
+    free when ``i`` is already current (the usual case) - ``torch.cuda.device`` costs microseconds."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, idx: int):
+        self.idx = idx
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def dequant(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, groupsize: int, bits: int, in_features: int,
@@ -93,10 +121,11 @@ def dequant(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g
     ori_dtype = scales.dtype
     f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales  # dq_torch_ops.cc:33-37
     n = qweight.size(1)
-    with torch.cuda.device(qweight.device):
+    idx = qweight.device.index
+    with _on_device(idx):
         out = torch.empty((in_features, n), dtype=torch.float16, device=qweight.device)
         st = lib.xbit_dequant_f16(out.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(), bits, groupsize,
-                                  in_features, n, bias, _stream_ptr(qweight.device))
+                                  in_features, n, bias, _stream_ptr(idx))
     _lib.check(st, "XbitOps.dequant")
     return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :40-42
 
@@ -123,10 +152,11 @@ def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
         mat_m *= input_a.size(1)
     ori_dtype = scales.dtype
     f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales  # :65-69
-    with torch.cuda.device(qweight.device):
+    idx = qweight.device.index
+    with _on_device(idx):
         out = torch.empty(shape, dtype=torch.float16, device=qweight.device)
         if mat_m > 0:
             st = lib.xbit_gemv_f16(out.data_ptr(), input_a.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(),
-                                   bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(qweight.device))
+                                   bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx))
             _lib.check(st, "XbitOps.gemv")
     return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :74-76
