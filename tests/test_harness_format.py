@@ -44,3 +44,36 @@ def test_replay_on_gpu(tmp_path, cuda_device):
     harness.save_sample(str(tmp_path), s)
     r = harness.replay(str(tmp_path), add_zero_bias=1, iters=3)
     assert r["dequant_errors"] == 0 and r["gemv_errors"] == 0 and r["gemv_ms"] > 0
+
+
+def test_cpp_replay_program_builds_without_torch():
+    """examples/replay_dataset.cc: a C++ host over the C ABI alone (the reference's harness executable,
+    main.cc).  Builds with hipcc, links libxbitops_hip and nothing of torch, and rejects bad usage."""
+    import subprocess
+
+    from xbitops_amd import build
+
+    exe = build.build_example()
+    deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libxbitops_hip.so" in deps and "torch" not in deps and "c10" not in deps
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_replay_program_on_gpu(tmp_path, cuda_device):
+    import subprocess
+
+    from xbitops_amd import build
+
+    exe = build.build_example()
+    s = _sample(k=2048, n=256, bits=3, g=128, bias=1)
+    harness.save_sample(str(tmp_path), s)
+    r = subprocess.run([exe, str(tmp_path), "1", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "dequant: 0 of" in r.stdout and "gemv:    0 of" in r.stdout
+    # a wrong golden output must be reported (exit status 1)
+    s.out = (s.out.astype(np.float32) + 0.5).astype(np.float16)
+    harness.save_sample(str(tmp_path), s)
+    r = subprocess.run([exe, str(tmp_path), "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 1, r.stdout + r.stderr

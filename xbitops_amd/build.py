@@ -78,5 +78,24 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False) ->
     return LIB
 
 
+EXAMPLE_SRC = os.path.normpath(os.path.join(HERE, "..", "examples", "replay_dataset.cc"))
+EXAMPLE_BIN = EXAMPLE_SRC[:-3]
+
+
+def build_example(force: bool = False) -> str:
+    """Build examples/replay_dataset: a C++ host program over the C ABI (no torch), the counterpart
+    of the reference's harness executable.  Needs the library (links -lxbitops_hip)."""
+    lib = build()
+    if not force and os.path.exists(EXAMPLE_BIN) and os.path.getmtime(EXAMPLE_BIN) >= max(os.path.getmtime(EXAMPLE_SRC), os.path.getmtime(lib)):
+        return EXAMPLE_BIN
+    inc = os.path.normpath(os.path.join(HERE, "..", "include"))
+    cmd = [hipcc(), "-O2", "-w", "-I", inc, EXAMPLE_SRC, "-o", EXAMPLE_BIN, "-L", LIB_DIR, "-lxbitops_hip", "-Wl,-rpath,$ORIGIN/../xbitops_amd/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building %s failed:\n%s\n%s" % (EXAMPLE_SRC, r.stdout, r.stderr))
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, keep_asm="--asm" in sys.argv, verbose=True)
+    print("built", build_example(force="--force" in sys.argv))
