@@ -23,17 +23,19 @@ __global__ void k_empty(uint32_t* out) {
 
 // tile kernel: NL lanes along N (each W bytes), 64/NL k-slots per wave, NW waves; each lane reads
 // LOADS consecutive rows starting at row (wave*LK + kl) * LOADS
-template <int W, int NL, int NW, int LOADS, bool NT>
+// ADJ: the 64/NL k-slots of a wave read ADJACENT rows in each instruction (row = base + i*LK + kl)
+// instead of rows LOADS apart (row = base + kl*LOADS + i)
+template <int W, int NL, int NW, int LOADS, bool NT, bool ADJ = false>
 __global__ void __launch_bounds__(64 * NW) k_tile(const uint32_t* __restrict__ w, uint32_t* out, uint32_t n_words, uint32_t rows) {
   constexpr int LK = 64 / NL, WW = W / 4;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, kl = lane / NL, nl = lane % NL;
   const uint32_t col = (blockIdx.x * NL + nl) * WW;
   uint32_t acc = 0;
-  for (uint32_t r0 = (wv * LK + kl) * LOADS; r0 < rows; r0 += NW * LK * LOADS) {
+  for (uint32_t r0 = ADJ ? wv * LK * LOADS + kl : (wv * LK + kl) * LOADS; r0 < rows; r0 += NW * LK * LOADS) {
     uint32_t v[LOADS][WW];
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      const uint32_t* src = w + (size_t)(r0 + i) * n_words + col;
+      const uint32_t* src = w + (size_t)(r0 + (ADJ ? i * LK : i)) * n_words + col;
       if constexpr (W == 8) {
         u32x2 t = NT ? __builtin_nontemporal_load((const u32x2*)src) : *(const u32x2*)src;
         v[i][0] = t.x; v[i][1] = t.y;
@@ -117,13 +119,14 @@ int main(int argc, char** argv) {
     if (s) hipExtLaunchKernel(f, g, b, args, 0, 0, s, e, 0);
     else hipLaunchKernel(f, g, b, args, 0, 0);
   };
-#define TILE_CASE(name, W, NL, NW, LOADS, NT)                                                            \
+#define TILE_CASE(name, W, NL, NW, LOADS, NT) TILE_CASE_A(name, W, NL, NW, LOADS, NT, false)
+#define TILE_CASE_A(name, W, NL, NW, LOADS, NT, ADJ)                                                     \
   for (int cp : {copies, 1})                                                                              \
     bench(name, bytes, cp, [&](int c, hipEvent_t s, hipEvent_t e) {                                       \
       const uint32_t* ptr = w + (size_t)c * words;                                                        \
       uint32_t nw = N, rows = K_ROWS;                                                                     \
       void* args[] = {&ptr, &out, &nw, &rows};                                                            \
-      ext((const void*)k_tile<W, NL, NW, LOADS, NT>, dim3(N / (NL * (W / 4))), dim3(64 * NW), args, s, e); \
+      ext((const void*)k_tile<W, NL, NW, LOADS, NT, ADJ>, dim3(N / (NL * (W / 4))), dim3(64 * NW), args, s, e); \
     });
 
   for (int cp : {1})
@@ -136,6 +139,9 @@ int main(int argc, char** argv) {
   TILE_CASE("tile 8B x16lanes(32col) NW16 8 loads nt", 8, 16, 16, 8, true)
   TILE_CASE("tile 12B x16lanes(48col) NW8 16 loads nt", 12, 16, 8, 16, true)
   TILE_CASE("tile 12B x16lanes(48col) NW8 16 loads", 12, 16, 8, 16, false)
+  TILE_CASE_A("tile 12B x16lanes(48col) NW8 16 loads, adjacent rows", 12, 16, 8, 16, false, true)
+  TILE_CASE_A("tile 16B x16lanes(64col) NW8 16 loads, adjacent rows", 16, 16, 8, 16, false, true)
+  TILE_CASE_A("tile 8B x16lanes(32col) NW8 16 loads, adjacent rows", 8, 16, 8, 16, false, true)
   TILE_CASE("tile 16B x16lanes(64col) NW8 16 loads nt", 16, 16, 8, 16, true)
   TILE_CASE("tile 16B x16lanes(64col) NW8 16 loads", 16, 16, 8, 16, false)
   TILE_CASE("tile 16B x16lanes(64col) NW16 8 loads nt", 16, 16, 16, 8, true)
