@@ -626,7 +626,11 @@ template <int BITS>
 int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
   constexpr int UBMAX = max_ub<BITS>();
   const uint32_t kblocks = (p.k + 31) / 32;
-  const int cpl = pick_cpl(p.n);
+  int cpl = pick_cpl(p.n);
+  if (variant >= 112 && variant <= 114) {  // sweep hook, any M: force the tile width of the default path (32/48/64 columns)
+    cpl = variant - 110;
+    variant = -1;
+  }
   if (p.groupsize % (32u * UBMAX) == 0) {
     if (variant >= 0 && p.m == 1) {  // tuning hooks (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
