@@ -425,3 +425,43 @@ def test_dequant_random_shapes_bit_exact(cuda_device):
         w = run_dequant(p, bias, cuda_device)
         w_ref = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, bias, oracle.RNE)
         assert np.array_equal(_bits(w), _bits(w_ref)), "case %d bits=%d k=%d n=%d g=%d bias=%d" % (case, bits, k, n, g, bias)
+
+
+def test_concurrent_streams_and_threads(cuda_device):
+    """include/xbitops_hip.h promises thread safety: four host threads, each on its own stream, run
+    split-K and plain GEMVs concurrently (split-K scratch is per stream); every result must equal
+    the single-threaded one bit for bit."""
+    import threading
+
+    import XbitOps
+
+    cases = []
+    for k, n, m in ((16384, 256, 1), (4096, 1024, 1), (14336, 512, 3)):
+        p = synth.make_problem(k, n, 4, 128, m=m, seed=k + n)
+        a, qw, sc, qz = to_dev(p, cuda_device)
+        want = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        cases.append((k, a, qw, sc, qz, want))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream(device=cuda_device)
+            with torch.cuda.stream(stream):
+                for it in range(40):
+                    k, a, qw, sc, qz, want = cases[(it + tid) % len(cases)]
+                    y = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+                    if it % 8 == 7:
+                        stream.synchronize()
+                        if not torch.equal(y, want):
+                            errors.append("thread %d iteration %d: result differs" % (tid, it))
+            stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (tid, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
