@@ -465,3 +465,29 @@ def test_concurrent_streams_and_threads(cuda_device):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_split_k_shape_inside_graph_capture(cuda_device):
+    """A split-K-eligible GEMV captured into a hipGraph: on a stream that has no scratch buffer yet
+    the launch must not allocate inside the capture (it runs unsplit); after a warm-up call the
+    captured launch is split.  Both graphs replay to the oracle's result."""
+    import XbitOps
+
+    k, n = 16384, 512
+    p = synth.make_problem(k, n, 4, 128, m=1, seed=99)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+    a, qw, sc, qz = to_dev(p, cuda_device)
+    for warm in (False, True):
+        stream = torch.cuda.Stream(device=cuda_device)  # a fresh stream: no scratch buffer of its own
+        with torch.cuda.stream(stream):
+            if warm:
+                XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+                stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                y = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+            for _ in range(3):
+                y.zero_()
+                graph.replay()
+            stream.synchronize()
+        assert_gemv_close(y.cpu().numpy(), y_ref, "graph replay, warm=%s" % warm)
