@@ -39,3 +39,32 @@ def test_quant_linear_forward(cuda_device):
         assert y.shape == (rows, 128)
         assert (y.float() - y_ref).abs().max() <= 2e-3 * y_ref.abs().max() + 1e-3
     assert layer(torch.zeros(2, 3, 512, device=cuda_device).half()).shape == (2, 3, 128)
+
+
+@pytest.mark.gpu
+def test_gemv_plan_equals_gemv(cuda_device):
+    """ops.GemvPlan (weight-side checks done once) gives the operator's result bit for bit, rejects
+    what the operator rejects, and QuantLinear rebuilds its plan when its buffers are replaced."""
+    import XbitOps
+    from xbitops_amd import ops, synth
+    from xbitops_amd.linear import QuantLinear
+
+    p = synth.make_problem(1024, 256, 4, 128, m=3, seed=11)
+    a, qw, sc, qz = (torch.from_numpy(x).to(cuda_device) for x in (p.act, p.qweight, p.scales, p.qzeros))
+    plan = ops.GemvPlan(qw, sc, qz, 128, 4, 1024, 1)
+    assert torch.equal(plan(a), XbitOps.gemv(a, qw, sc, qz, 128, 4, 1024, 1))
+    a3 = a.reshape(1, 3, 1024)
+    assert torch.equal(plan(a3), XbitOps.gemv(a3, qw, sc, qz, 128, 4, 1024, 1))
+    with pytest.raises(RuntimeError):
+        plan(a.float())
+    with pytest.raises(RuntimeError):
+        plan(a[:, :512].contiguous())
+    with pytest.raises(RuntimeError):
+        ops.GemvPlan(qw, sc, qz, 128, 4, 1000, 1)  # in_features does not match qweight
+    layer = QuantLinear.from_float(torch.randn(512, 64) * 0.05, bits=4, groupsize=128).to(cuda_device)
+    x = (torch.randn(2, 512, device=cuda_device) * 0.5).half()
+    y1 = layer(x)
+    first = layer._plan
+    assert layer(x) is not None and layer._plan is first
+    layer.qweight = layer.qweight.clone()  # a replaced buffer: the plan must follow
+    assert torch.equal(layer(x), y1) and layer._plan is not first

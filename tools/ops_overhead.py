@@ -33,6 +33,8 @@ def main():
     sp = torch.cuda.current_stream(dev).cuda_stream
     ptrs = (out.data_ptr(), a.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr())
     print("XbitOps.gemv (full operator)            %6.2f us" % timeit(lambda: XbitOps.gemv(a, qw, sc, qz, 128, 4, 4096, 1)))
+    plan = ops.GemvPlan(qw, sc, qz, 128, 4, 4096, 1)
+    print("ops.GemvPlan call (weight checks hoisted)  %6.2f us" % timeit(lambda: plan(a)))
     print("  raw ctypes call, cached pointers      %6.2f us" % timeit(lambda: lib.xbit_gemv_f16(*ptrs, 4, 128, 1, 4096, 11008, 1, sp)))
     print("  argument checks only                  %6.2f us" % timeit(lambda: (ops._check_input(a, "input_a"), ops._check_common(qw, sc, qz, 128, 4, 4096))))
     print("  torch.empty output                    %6.2f us" % timeit(lambda: torch.empty((1, 11008), dtype=torch.float16, device=dev)))

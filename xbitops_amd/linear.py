@@ -28,6 +28,7 @@ class QuantLinear(torch.nn.Module):
         self.register_buffer("scales", torch.zeros((groups, out_features), dtype=torch.float16))
         self.register_buffer("qzeros", torch.zeros((groups, packing.packed_rows(out_features, bits)), dtype=torch.int32))
         self.bias = torch.nn.Parameter(torch.zeros(out_features, dtype=torch.float16)) if bias else None
+        self._plan = None  # ops.GemvPlan for the current buffers (rebuilt when .to() / load_state_dict replaces them)
 
     @classmethod
     def from_float(cls, weight_kn, bits: int, groupsize: int = 128, add_zero_bias: int = 0) -> "QuantLinear":
@@ -48,7 +49,10 @@ class QuantLinear(torch.nn.Module):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.in_features).to(torch.float16).contiguous()
         if x2.shape[0] <= GEMV_MAX_ROWS:
-            y = ops.gemv(x2, self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
+            plan = self._plan
+            if plan is None or not plan.matches(self.qweight, self.scales, self.qzeros):
+                plan = self._plan = ops.GemvPlan(self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
+            y = plan(x2)
         else:
             y = x2 @ self.dequantize()
         if self.bias is not None:

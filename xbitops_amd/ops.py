@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["dequant", "gemv"]
+__all__ = ["dequant", "gemv", "GemvPlan"]
 
 
 def _check_input(t: torch.Tensor, name: str) -> None:
@@ -160,3 +160,56 @@ def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
                                    bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx))
             _lib.check(st, "XbitOps.gemv")
     return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :74-76
+
+
+class GemvPlan:
+    """The checks of :func:`gemv` done once for a fixed set of weight tensors (a module's buffers).
+
+    ``plan = GemvPlan(qweight, scales, qzeros, groupsize, bits, in_features, add_zero_bias)`` validates
+    exactly as ``gemv`` does; ``plan(input_a)`` then only checks the activation and launches.  Saves
+    the per-call validation of the weight-side tensors (about a quarter of the host cost of a call);
+    the result is identical to ``gemv(input_a, ...)``.  The plan holds references to the tensors;
+    build a new one if a buffer is replaced (``plan.matches`` tells).
+    """
+
+    __slots__ = ("qweight", "scales", "qzeros", "f16_scale", "groupsize", "bits", "in_features", "bias", "n", "idx", "ptrs", "bf16", "lib")
+
+    def __init__(self, qweight, scales, qzeros, groupsize: int, bits: int, in_features: int, add_zero_bias: int):
+        self.groupsize, self.bits, self.in_features = int(groupsize), int(bits), int(in_features)
+        self.bias = add_zero_bias_check(add_zero_bias)
+        _check_common(qweight, scales, qzeros, self.groupsize, self.bits, self.in_features)
+        self.qweight, self.scales, self.qzeros = qweight, scales, qzeros
+        self.bf16 = scales.dtype == torch.bfloat16
+        self.f16_scale = scales.to(torch.float16) if self.bf16 else scales
+        self.n = qweight.size(1)
+        self.idx = qweight.device.index
+        self.ptrs = (qweight.data_ptr(), self.f16_scale.data_ptr(), qzeros.data_ptr())
+        self.lib = _lib.load()
+
+    def matches(self, qweight, scales, qzeros) -> bool:
+        return qweight is self.qweight and scales is self.scales and qzeros is self.qzeros
+
+    def __call__(self, input_a: torch.Tensor) -> torch.Tensor:
+        if not input_a.is_cuda or not input_a.is_contiguous():
+            _check_input(input_a, "input_a")
+        if input_a.device.index != self.idx:
+            raise RuntimeError("input and weight must be on the same device")
+        if input_a.dtype != torch.float16:
+            raise RuntimeError("input_a must be float16")
+        dim = input_a.dim()
+        if dim not in (2, 3) or input_a.size(-1) != self.in_features:
+            raise RuntimeError("input_a must be [B, in_features] or [B, S, in_features], got %s" % (tuple(input_a.shape),))
+        if dim == 2:
+            mat_m = input_a.size(0)
+            shape = (mat_m, self.n)
+        else:
+            shape = (input_a.size(0), input_a.size(1), self.n)
+            mat_m = shape[0] * shape[1]
+        with _on_device(self.idx):
+            out = torch.empty(shape, dtype=torch.float16, device=input_a.device)
+            if mat_m > 0:
+                st = self.lib.xbit_gemv_f16(out.data_ptr(), input_a.data_ptr(), self.ptrs[0], self.ptrs[1], self.ptrs[2], self.bits,
+                                            self.groupsize, mat_m, self.in_features, self.n, self.bias, _stream_ptr(self.idx))
+                if st != 0:
+                    _lib.check(st, "XbitOps.gemv")
+        return out.to(torch.bfloat16) if self.bf16 else out
