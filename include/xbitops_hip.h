@@ -83,6 +83,16 @@ int xbit_dequant_f16(void* out, const void* qweight, const void* scales, const v
 int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
                   int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream);
 
+/* Extension (not in the reference): one activation against `count` (1..4) weight sets that share k,
+ * bits and groupsize - q/k/v or gate/up of a decoder layer - in ONE launch when the shape allows
+ * (m == 1 and the fast path's alignment rules), otherwise as `count` xbit_gemv_f16 launches; results
+ * as xbit_gemv_f16 per set.  outs / qweights / scales / qzeros / ns are HOST arrays of `count`
+ * device pointers / column counts.  Small layers sit on the ~4 us launch floor, which only fewer
+ * launches remove: three 4096x4096 w4 GEMVs take 3 x 4.3 us, fused 6.9 us. */
+int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void* const* qweights, const void* const* scales,
+                        const void* const* qzeros, const uint32_t* ns, int bits, int groupsize, uint32_t m, uint32_t k,
+                        uint8_t add_zero_bias, void* hip_stream);
+
 /* Measurement aid (not part of the reference's surface; used by bench.py only).
  * While enabled on the calling host thread, every launch made by that thread is bracketed by a
  * pair of HIP events that record the kernel's own begin/end on the device (hipExtLaunchKernel),

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--group", type=int, default=128)
     ap.add_argument("--layers", type=int, default=0, help="weight sets to rotate over (default: the model's layer count, capped by memory)")
     ap.add_argument("--replays", type=int, default=20)
+    ap.add_argument("--fused", action="store_true", help="q/k/v in one launch and gate/up in one launch (xbit_gemv_multi_f16)")
     args = ap.parse_args()
     hid, inter, kv, nlayers = MODELS[args.model]
     shapes = [("q", hid, hid), ("k", hid, kv), ("v", hid, kv), ("o", hid, hid), ("gate", hid, inter), ("up", hid, inter), ("down", inter, hid)]
@@ -51,7 +52,26 @@ def main():
         sets.append((k, n, act, out, qws, sc, qz))
     torch.cuda.synchronize()
 
+    import ctypes
+
+    vp = ctypes.c_void_p
+
+    def fused(group, i, sp):
+        c = len(group)
+        k, act = group[0][0], group[0][2]
+        st = lib.xbit_gemv_multi_f16(c, (vp * c)(*[g[3].data_ptr() for g in group]), act.data_ptr(), (vp * c)(*[g[4][i].data_ptr() for g in group]),
+                                     (vp * c)(*[g[5].data_ptr() for g in group]), (vp * c)(*[g[6].data_ptr() for g in group]),
+                                     (ctypes.c_uint32 * c)(*[g[1] for g in group]), args.bits, args.group, 1, k, 1, sp)
+        if st != 0:
+            _lib.check(st, "xbit_gemv_multi_f16")
+
     def run_layer(i, sp):
+        if args.fused:  # sets: q k v o gate up down
+            fused(sets[0:3], i, sp)
+            fused(sets[3:4], i, sp)
+            fused(sets[4:6], i, sp)
+            fused(sets[6:7], i, sp)
+            return
         for k, n, act, out, qws, sc, qz in sets:
             st = lib.xbit_gemv_f16(out.data_ptr(), act.data_ptr(), qws[i].data_ptr(), sc.data_ptr(), qz.data_ptr(), args.bits, args.group, 1, k, n, 1, sp)
             if st != 0:
@@ -73,7 +93,9 @@ def main():
         graph.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (args.replays * layers)
-    print("model %s w%d g%d: %d linear launches per layer, %.1f MB per layer, %d weight sets (%.1f GB)" % (
+    if args.fused:
+        print("FUSED: q/k/v and gate/up share a launch (4 launches per layer)")
+    print("model %s w%d g%d: %d linear layers per layer, %.1f MB per layer, %d weight sets (%.1f GB)" % (
         args.model, args.bits, args.group, len(shapes), layer_bytes / 1e6, layers, layers * layer_bytes / 1e9))
     print("  %.2f us per decoder layer (linear layers, hipGraph replay, cold weights)  = %.0f GB/s algorithmic = %.1f %% of 8 TB/s" % (
         dt * 1e6, layer_bytes / dt / 1e9, layer_bytes / dt / 8e12 * 100))

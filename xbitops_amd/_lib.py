@@ -21,6 +21,7 @@ EXPORTS = (
     "xbit_status_string",
     "xbit_dequant_f16",
     "xbit_gemv_f16",
+    "xbit_gemv_multi_f16",
     "xbit_profile_enable",
     "xbit_profile_last_ms",
 )
@@ -59,6 +60,9 @@ def load() -> ctypes.CDLL:
     lib.xbit_dequant_f16.argtypes = [vp, vp, vp, vp, ci, ci, u32, u32, u8, vp]
     lib.xbit_gemv_f16.restype = ci
     lib.xbit_gemv_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, u32, u32, u32, u8, vp]
+    lib.xbit_gemv_multi_f16.restype = ci
+    lib.xbit_gemv_multi_f16.argtypes = [ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                        ctypes.POINTER(u32), ci, ci, u32, u32, u8, vp]
     lib.xbit_profile_enable.restype = ci
     lib.xbit_profile_enable.argtypes = [ci]
     lib.xbit_profile_last_ms.restype = ci

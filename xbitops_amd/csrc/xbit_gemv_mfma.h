@@ -106,9 +106,14 @@ struct RowLoad {
 //        partial sums meet in per-element 64-bit fixed-point accumulators (one returning atomic
 //        per element and workgroup, see the epilogue).  For few column tiles and long K
 //        (down-projections), where whole-K tiles leave CUs idle.
-template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0, bool SPLIT = false>
-__global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) {
+//   MULTI  fused launch: the grid covers the column tiles of up to 4 weight sets that share K, the
+//        bit-width, the group size and the activation (q/k/v, gate/up); a workgroup looks up its set.
+//        A separate template (gemv_mfma_multi_kernel below shares this body through the MULTI flag
+//        and takes the larger argument block), so the plain kernels are compiled exactly as before.
+template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0, bool SPLIT = false, bool MULTI = false>
+__global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::conditional_t<MULTI, GemvMultiParams, GemvParams> p) {
   static_assert(!SPLIT || GUARD, "split-K launches use the guarded build");
+  static_assert(!MULTI || (GUARD && !SPLIT && ABLATE == 0), "fused launches use the guarded, unsplit build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
   constexpr int LK = 64 / NL;                // k-slots per wave
@@ -145,12 +150,28 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   const int nwaves = (int)(blockDim.x >> 6);   // <= NW
   const uint32_t T = (uint32_t)(LK * nwaves);  // k-batches per workgroup sweep
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
-  const uint32_t tile = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t tile_g = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);  // tile of the whole grid
+  // this workgroup's weight set: the only one (p.n, p.qweight, ...) or, fused, set j of p.multi_*
+  uint32_t tile = tile_g, n_ = p.n, zw_ = p.zw;
+  const uint32_t* qweight_ = p.qweight;
+  const uint16_t* scales_ = p.scales;
+  const uint32_t* qzeros_ = p.qzeros;
+  uint16_t* out_ = p.out;
+  if constexpr (MULTI) {
+    const uint32_t j = (tile_g >= p.multi_tile_end[0] ? 1u : 0u) + (tile_g >= p.multi_tile_end[1] ? 1u : 0u) + (tile_g >= p.multi_tile_end[2] ? 1u : 0u);
+    tile = tile_g - (j ? p.multi_tile_end[j - 1] : 0u);
+    n_ = p.multi_n[j];
+    zw_ = p.multi_zw[j];
+    qweight_ = p.multi_qweight[j];
+    scales_ = p.multi_scales[j];
+    qzeros_ = p.multi_qzeros[j];
+    out_ = p.multi_out[j];
+  }
   const uint32_t b_begin = SPLIT ? split * p.bps : 0u;
   const uint32_t b_end = SPLIT ? (b_begin + p.bps < p.batches ? b_begin + p.bps : p.batches) : p.batches;
   const uint32_t k_end = SPLIT ? (b_end * (uint32_t)(UB * 32) < p.k ? b_end * (uint32_t)(UB * 32) : p.k) : p.k;  // activations beyond: 0
   const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
-  const bool col_ok = GUARD ? col < p.n : true;  // n % CPL == 0 is NOT required: stores are per column
+  const bool col_ok = GUARD ? col < n_ : true;  // n % CPL == 0 is NOT required: stores are per column
   const uint32_t m0 = blockIdx.y * MT;
   uint32_t* const my_act = s_act + wv * ACT_DW;
   // A fragment of this lane = row (lane & 15), k-octet (lane >> 4) of the MFMA's A tile.
@@ -170,11 +191,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
   }
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
-  const uint32_t row_bytes = p.n * 4u;  // one packed row
+  const uint32_t row_bytes = n_ * 4u;  // one packed row
 
-  const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
-  const rsrc_t r_s = make_rsrc(p.scales, p.groups * p.n * 2u);
-  const rsrc_t r_z = make_rsrc(p.qzeros, p.groups * p.zw * 4u);
+  const rsrc_t r_w = make_rsrc(qweight_, p.kw * row_bytes);
+  const rsrc_t r_s = make_rsrc(scales_, p.groups * n_ * 2u);
+  const rsrc_t r_z = make_rsrc(qzeros_, p.groups * zw_ * 4u);
   const rsrc_t r_a = make_rsrc(p.a, p.m * p.k * 2u);
 
   f4_t acc[CPL];
@@ -212,7 +233,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
     uint32_t sbits[CPL];
     {
       // CPL fp16 scales starting at half index h0: one 4- or 8-byte load from the enclosing dword(s)
-      const uint32_t h0 = gi * p.n + col;
+      const uint32_t h0 = gi * n_ + col;
       uint32_t soff = (h0 & ~1u) * 2u;
       if (GUARD && !active) soff = kOob;
       if constexpr (CPL == 2) {  // col and n are even: h0 is even
@@ -232,7 +253,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
     uint32_t zwin;
     {
       const uint32_t bit = col * BITS, sh = bit & 31u;
-      const uint32_t zoff = (gi * p.zw + (bit >> 5)) * 4u;
+      const uint32_t zoff = (gi * zw_ + (bit >> 5)) * 4u;
       if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
         zwin = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0) >> sh;  // the CPL fields never straddle a word
       } else {
@@ -412,7 +433,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
     float sum = 0.f;
     for (int v = 0; v < nwaves * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
     const uint32_t n_out = tile * CN + c, row = m0 + m;
-    const bool valid = !GUARD || (n_out < p.n && row < p.m);
+    const bool valid = !GUARD || (n_out < n_ && row < p.m);
     if constexpr (SPLIT) {
       // Cross-workgroup reduction in ONE trip to the device coherence point: the partial sum is
       // added to the element's 64-bit accumulator as a fixed-point integer (2^-28 units, biased
@@ -422,7 +443,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
       // then clears the slot for the next launch.  Layout: bits 0-55 sum of (v + 2^51), 56-59
       // arrivals, 60-63 arrivals whose partial sum was not finite / out of range (-> NaN).
       if (valid) {
-        unsigned long long* slot = p.acc + ((size_t)blockIdx.y * p.tiles + tile) * (size_t)(MT * CN) + e;
+        unsigned long long* slot = p.acc + ((size_t)blockIdx.y * p.tiles + tile_g) * (size_t)(MT * CN) + e;
         const bool fin = __builtin_fabsf(sum) < 8388608.0f;  // 2^23; false for NaN / Inf too
         const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;  // |v| < 2^51
         const unsigned long long add = (unsigned long long)(v + (1ll << 51)) + (1ull << 56) + (fin ? 0ull : (1ull << 60));
@@ -432,12 +453,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) 
           const long long fixed = (long long)(tot & ((1ull << 56) - 1ull)) - (long long)p.splits * (1ll << 51);
           float y = (float)fixed * (1.0f / 268435456.0f);
           if (tot >> 60) y = __builtin_nanf("");
-          p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)y);
+          out_[(size_t)row * n_ + n_out] = as_u16((_Float16)y);
           __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     } else {
-      if (valid) p.out[(size_t)row * p.n + n_out] = as_u16((_Float16)sum);
+      if (valid) out_[(size_t)row * n_ + n_out] = as_u16((_Float16)sum);
     }
   }
   if constexpr (ABLATE & 8) {
@@ -620,6 +641,42 @@ int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl) {
     case 3: return launch_rows<BITS, UB, 3, 16, NT>(p, stream);
     default: return launch_rows<BITS, UB, 2, 16, NT>(p, stream);
   }
+}
+
+// fused launch (MULTI): up to kMaxMulti weight sets, M = 1, 16-lane tiles of 16*CPL columns
+template <int BITS, int UB, int CPL, int NW>
+int launch_multi_one(GemvMultiParams p, hipStream_t stream, uint32_t waves) {
+  constexpr uint32_t CN = 16 * CPL;
+  uint32_t end = 0;
+  for (uint32_t j = 0; j < (uint32_t)kMaxMulti; ++j) {
+    if (j < p.multi_count) end += (p.multi_n[j] + CN - 1) / CN;
+    p.multi_tile_end[j] = j < p.multi_count ? end : 0xFFFFFFFFu;
+  }
+  p.tiles = end;
+  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
+  dim3 grid(p.tiles, 1), block(64 * (waves < (uint32_t)NW ? waves : (uint32_t)NW));
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, 1, false, true, 0, lookahead_for<BITS>(), false, true>, grid, block, stream, p);
+}
+
+template <int BITS>
+int launch_multi_bits(const GemvMultiParams& p, hipStream_t stream) {
+  constexpr int UBMAX = max_ub<BITS>();
+  if (p.m != 1 || p.groupsize % (32u * UBMAX) != 0) return XBIT_ERR_SHAPE;  // caller launches one by one
+  uint32_t total_n = 0;
+  for (uint32_t j = 0; j < p.multi_count; ++j) total_n += p.multi_n[j];
+  const int cpl = pick_cpl(total_n);  // the width the concatenated layer would get
+  uint32_t tiles = 0;
+  for (uint32_t j = 0; j < p.multi_count; ++j) tiles += (p.multi_n[j] + 16u * cpl - 1) / (16u * cpl);
+  const uint32_t batches = ((p.k + 31) / 32 + UBMAX - 1) / UBMAX;
+  const uint32_t waves = sweep_waves(batches, 4, tiles <= 240u ? 16u : 8u);
+  if (waves <= 8u) {
+    if (cpl == 4) return launch_multi_one<BITS, UBMAX, 4, 8>(p, stream, waves);
+    if (cpl == 3) return launch_multi_one<BITS, UBMAX, 3, 8>(p, stream, waves);
+    return launch_multi_one<BITS, UBMAX, 2, 8>(p, stream, waves);
+  }
+  if (cpl == 4) return launch_multi_one<BITS, UBMAX, 4, 16>(p, stream, waves);
+  if (cpl == 3) return launch_multi_one<BITS, UBMAX, 3, 16>(p, stream, waves);
+  return launch_multi_one<BITS, UBMAX, 2, 16>(p, stream, waves);
 }
 
 template <int BITS>

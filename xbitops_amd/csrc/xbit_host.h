@@ -19,6 +19,8 @@ struct DequantParams {
   uint32_t k, n, groupsize, kw, groups, zw, bias, kblocks;
 };
 
+constexpr int kMaxMulti = 4;  // weight sets one fused launch can take (xbit_gemv_multi_f16)
+
 struct GemvParams {
   uint16_t* out;            // fp16 [m, n]
   const uint16_t* a;        // fp16 [m, k]
@@ -35,6 +37,19 @@ struct GemvParams {
   // also counts arrivals, and the thread that sees the last arrival writes the fp16 result.
   uint32_t splits, bps;
   unsigned long long* acc;  // [grid.y][tiles][MT * CN], zero between launches (the last arriver resets its slot)
+};
+
+// Fused launches (MULTI builds of the kernel): several weight sets with the same K / bits / group size
+// and ONE activation (q/k/v, gate/up) share a grid; tile t belongs to set j with
+// multi_tile_end[j-1] <= t < multi_tile_end[j].  A separate kernel-argument type: the plain kernels keep
+// their argument block (and their code) unchanged.
+struct GemvMultiParams : GemvParams {
+  uint32_t multi_count;
+  uint32_t multi_tile_end[kMaxMulti], multi_n[kMaxMulti], multi_zw[kMaxMulti];
+  const uint32_t* multi_qweight[kMaxMulti];
+  const uint16_t* multi_scales[kMaxMulti];
+  const uint32_t* multi_qzeros[kMaxMulti];
+  uint16_t* multi_out[kMaxMulti];
 };
 
 // Per-(device, stream) scratch for split-K launches: launches on one stream run in order, so they
@@ -69,6 +84,8 @@ int launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, 
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
 int launch_gemv(const GemvParams& p, int bits, hipStream_t stream);                        // dispatcher (xbit_gemv.hip)
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int variant);     // xbit_gemv_mfma.hip
+// fused launch over p.multi_* (M = 1); XBIT_ERR_SHAPE when the shape is not eligible (caller then launches one by one)
+int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
 
 // tuning hooks (tools/ only): variant < 0 = automatic; trace buffer for the stamped build
 int gemv_variant_override();

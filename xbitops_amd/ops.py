@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["dequant", "gemv", "GemvPlan"]
+__all__ = ["dequant", "gemv", "gemv_multi", "GemvPlan"]
 
 
 def _check_input(t: torch.Tensor, name: str) -> None:
@@ -160,6 +160,49 @@ def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
                                    bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx))
             _lib.check(st, "XbitOps.gemv")
     return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :74-76
+
+
+def gemv_multi(input_a: torch.Tensor, weights, groupsize: int, bits: int, in_features: int, add_zero_bias: int):
+    """Extension (not in the reference): ``[gemv(input_a, qw, sc, qz, ...) for (qw, sc, qz) in weights]`` for
+    1..4 weight sets that share ``in_features``, ``bits`` and ``groupsize`` (q/k/v, gate/up) - in ONE
+    kernel launch at batch 1.  Same checks and results as :func:`gemv` per set; returns a list."""
+    import ctypes
+
+    groupsize, bits, in_features = int(groupsize), int(bits), int(in_features)
+    bias = add_zero_bias_check(add_zero_bias)
+    weights = list(weights)
+    if not 1 <= len(weights) <= 4:
+        raise RuntimeError("gemv_multi takes 1 to 4 weight sets")
+    _check_input(input_a, "input_a")
+    if input_a.dtype != torch.float16:
+        raise RuntimeError("input_a must be float16")
+    if input_a.dim() not in (2, 3) or input_a.size(-1) != in_features:
+        raise RuntimeError("input_a must be [B, in_features] or [B, S, in_features], got %s" % (tuple(input_a.shape),))
+    bf16 = []
+    for qw, sc, qz in weights:
+        _check_common(qw, sc, qz, groupsize, bits, in_features)
+        if qw.device != input_a.device:
+            raise RuntimeError("input and weight must be on the same device")
+        bf16.append(sc.dtype == torch.bfloat16)
+    lib = _lib.load()
+    lead = tuple(input_a.shape[:-1])
+    mat_m = 1
+    for d in lead:
+        mat_m *= d
+    f16_scales = [sc.to(torch.float16) if b else sc for (_qw, sc, _qz), b in zip(weights, bf16)]
+    idx = input_a.device.index
+    count = len(weights)
+    vp = ctypes.c_void_p
+    with _on_device(idx):
+        outs = [torch.empty(lead + (qw.size(1),), dtype=torch.float16, device=input_a.device) for qw, _sc, _qz in weights]
+        if mat_m > 0:
+            st = lib.xbit_gemv_multi_f16(
+                count, (vp * count)(*[o.data_ptr() for o in outs]), input_a.data_ptr(),
+                (vp * count)(*[qw.data_ptr() for qw, _s, _z in weights]), (vp * count)(*[s.data_ptr() for s in f16_scales]),
+                (vp * count)(*[qz.data_ptr() for _q, _s, qz in weights]), (ctypes.c_uint32 * count)(*[qw.size(1) for qw, _s, _z in weights]),
+                bits, groupsize, mat_m, in_features, bias, _stream_ptr(idx))
+            _lib.check(st, "XbitOps.gemv_multi")
+    return [o.to(torch.bfloat16) if b else o for o, b in zip(outs, bf16)]
 
 
 class GemvPlan:
