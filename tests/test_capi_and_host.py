@@ -37,8 +37,9 @@ def test_library_has_no_torch_dependency(native_lib):
     import subprocess
 
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    assert "torch" not in out and "c10" not in out
-    assert "amdhip64" in out
+    names = [line.split()[0] for line in out.splitlines() if line.strip()]  # names only: the load addresses are random hex
+    assert not any("torch" in n or "c10" in n for n in names), names
+    assert any("amdhip64" in n for n in names)
 
 
 def test_status_strings(native_lib):

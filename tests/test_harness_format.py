@@ -55,7 +55,9 @@ def test_cpp_replay_program_builds_without_torch():
 
     exe = build.build_example()
     deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
-    assert "libxbitops_hip.so" in deps and "torch" not in deps and "c10" not in deps
+    names = [line.split()[0] for line in deps.splitlines() if line.strip()]  # library names only (addresses are random hex)
+    assert any(n.startswith("libxbitops_hip.so") for n in names)
+    assert not any("torch" in n or "c10" in n for n in names), names
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
 

@@ -68,3 +68,23 @@ def test_gemv_plan_equals_gemv(cuda_device):
     assert layer(x) is not None and layer._plan is first
     layer.qweight = layer.qweight.clone()  # a replaced buffer: the plan must follow
     assert torch.equal(layer(x), y1) and layer._plan is not first
+
+
+@pytest.mark.gpu
+def test_quant_linear_group(cuda_device):
+    """QuantLinearGroup: one token -> one fused launch, outputs equal to the layers' own."""
+    from xbitops_amd.linear import QuantLinear, QuantLinearGroup
+
+    torch.manual_seed(1)
+    layers = [QuantLinear.from_float(torch.randn(1024, n) * 0.05, bits=4, groupsize=128, add_zero_bias=1).to(cuda_device) for n in (256, 128, 128)]
+    group = QuantLinearGroup(layers)
+    for rows in (1, 3):
+        x = (torch.randn(rows, 1024, device=cuda_device) * 0.5).half()
+        ys = group(x)
+        assert len(ys) == 3
+        for layer, y in zip(layers, ys):
+            want = layer(x)
+            assert y.shape == want.shape
+            assert (y.float() - want.float()).abs().max() <= 1e-3 * want.float().abs().max() + 2.0 ** -14
+    with pytest.raises(ValueError):
+        QuantLinearGroup([layers[0], QuantLinear.from_float(torch.randn(512, 64) * 0.05, bits=4, groupsize=128).to(cuda_device)])

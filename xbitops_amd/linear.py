@@ -58,3 +58,40 @@ class QuantLinear(torch.nn.Module):
         if self.bias is not None:
             y = y + self.bias
         return y.reshape(*lead, self.out_features)
+
+
+class QuantLinearGroup(torch.nn.Module):
+    """Several :class:`QuantLinear` layers that read the SAME input (q/k/v, gate/up).
+
+    ``forward(x)`` returns the list of their outputs.  A single token (one row) goes through
+    ``ops.gemv_multi`` - one kernel launch for the whole group instead of one per layer, which is what
+    the small layers of a decoder need (they sit on the launch floor); anything else runs the layers
+    one by one.  The layers must share ``in_features``, ``bits``, ``groupsize`` and ``add_zero_bias``.
+    """
+
+    def __init__(self, layers):
+        super().__init__()
+        layers = list(layers)
+        if not 1 <= len(layers) <= 4:
+            raise ValueError("a group holds 1 to 4 layers")
+        first = layers[0]
+        for layer in layers[1:]:
+            if (layer.in_features, layer.bits, layer.groupsize, layer.add_zero_bias) != (first.in_features, first.bits, first.groupsize, first.add_zero_bias):
+                raise ValueError("grouped layers must share in_features, bits, groupsize and add_zero_bias")
+        self.layers = torch.nn.ModuleList(layers)
+
+    def forward(self, x: torch.Tensor):
+        first = self.layers[0]
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, first.in_features)
+        if x2.shape[0] != 1:
+            return [layer(x) for layer in self.layers]
+        x2 = x2.to(torch.float16).contiguous()
+        ys = ops.gemv_multi(x2, [(layer.qweight, layer.scales, layer.qzeros) for layer in self.layers], first.groupsize, first.bits,
+                            first.in_features, first.add_zero_bias)
+        out = []
+        for layer, y in zip(self.layers, ys):
+            if layer.bias is not None:
+                y = y + layer.bias
+            out.append(y.reshape(*lead, layer.out_features))
+        return out
