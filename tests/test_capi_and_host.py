@@ -113,3 +113,13 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.XbitLibraryError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_public_header_is_plain_c():
+    """include/xbitops_hip.h is the drop-in boundary: it must compile as C99 and as C++ on its own."""
+    import subprocess
+
+    hdr = os.path.join(ROOT, "include", "xbitops_hip.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], ["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
