@@ -85,7 +85,7 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
 
 /* Extension (not in the reference): one activation against `count` (1..4) weight sets that share k,
  * bits and groupsize - q/k/v or gate/up of a decoder layer - in ONE launch when the shape allows
- * (m == 1 and the fast path's alignment rules), otherwise as `count` xbit_gemv_f16 launches; results
+ * (m <= 4 and the fast path's alignment rules), otherwise as `count` xbit_gemv_f16 launches; results
  * as xbit_gemv_f16 per set.  outs / qweights / scales / qzeros / ns are HOST arrays of `count`
  * device pointers / column counts.  Small layers sit on the ~4 us launch floor, which only fewer
  * launches remove: three 4096x4096 w4 GEMVs take 3 x 4.3 us, fused 6.9 us. */

@@ -496,13 +496,14 @@ def test_split_k_shape_inside_graph_capture(cuda_device):
 @pytest.mark.parametrize("bits", [3, 4, 8])
 def test_gemv_multi_fused_launch(bits, cuda_device):
     """xbit_gemv_multi_f16: q/k/v-style (equal N), gate/up-style, ragged and single sets in one launch at
-    batch 1; batch > 1 and group sizes the fused build does not take fall back to one launch per
+    1..4 rows; more rows and group sizes the fused build does not take fall back to one launch per
     set.  Every output is checked against the oracle and against the single-set operator."""
     import XbitOps
     from xbitops_amd import ops
 
     for k, ns, g, m in ((4096, (1024, 1024, 1024), 128, 1), (2048, (2752, 2752), 128, 1), (1024, (130, 66, 258, 34), 128, 1),
-                        (2048, (512,), 128, 1), (1024, (256, 512), 128, 3), (1024, (256, 256), 32, 1), (8192, (96, 160), 128, 1)):
+                        (2048, (512,), 128, 1), (1024, (256, 512), 128, 3), (2048, (1024, 1024, 512), 128, 4), (1024, (256, 130), 128, 6),
+                        (1024, (256, 256), 32, 1), (8192, (96, 160), 128, 1)):
         sets, refs = [], []
         act = None
         for j, n in enumerate(ns):

@@ -177,8 +177,8 @@ int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void*
   if (m == 0 || (uint64_t)m * k >= (1ull << 40)) return XBIT_ERR_SHAPE;
   if ((uintptr_t)a & 1u) return XBIT_ERR_ALIGNMENT;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  // one fused launch when the shape allows it (batch 1, the fast path's alignment and size limits) ...
-  bool fused = count >= 2 && m == 1 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 16 == 0) && xbit::gemv_variant_override() < 0;
+  // one fused launch when the shape allows it (up to 4 rows, the fast path's alignment and size limits) ...
+  bool fused = count >= 2 && m <= 4 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 16 == 0) && xbit::gemv_variant_override() < 0;
   for (int j = 0; j < count && fused; ++j)
     fused = ((uint64_t)xbit::packed_rows(k, bits) * ns[j] * 4u < (1ull << 31)) && ((uintptr_t)qweights[j] % 4 == 0);
   if (fused) {

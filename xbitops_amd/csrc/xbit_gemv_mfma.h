@@ -643,9 +643,9 @@ int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl) {
   }
 }
 
-// fused launch (MULTI): up to kMaxMulti weight sets, M = 1, 16-lane tiles of 16*CPL columns
-template <int BITS, int UB, int CPL, int NW>
-int launch_multi_one(GemvMultiParams p, hipStream_t stream, uint32_t waves) {
+// fused launch (MULTI): up to kMaxMulti weight sets, M <= 4, 16-lane tiles of 16*CPL columns
+template <int BITS, int UB, int CPL, int NW, int MT>
+int launch_multi_mt(GemvMultiParams p, hipStream_t stream, uint32_t waves) {
   constexpr uint32_t CN = 16 * CPL;
   uint32_t end = 0;
   for (uint32_t j = 0; j < (uint32_t)kMaxMulti; ++j) {
@@ -654,14 +654,20 @@ int launch_multi_one(GemvMultiParams p, hipStream_t stream, uint32_t waves) {
   }
   p.tiles = end;
   p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  dim3 grid(p.tiles, 1), block(64 * (waves < (uint32_t)NW ? waves : (uint32_t)NW));
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, 1, false, true, 0, lookahead_for<BITS>(), false, true>, grid, block, stream, p);
+  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * (waves < (uint32_t)NW ? waves : (uint32_t)NW));
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, MT, false, true, 0, lookahead_for<BITS>(), false, true>, grid, block, stream, p);
+}
+
+template <int BITS, int UB, int CPL, int NW>
+int launch_multi_one(const GemvMultiParams& p, hipStream_t stream, uint32_t waves) {
+  if (p.m == 1) return launch_multi_mt<BITS, UB, CPL, NW, 1>(p, stream, waves);
+  return launch_multi_mt<BITS, UB, CPL, NW, 4>(p, stream, waves);
 }
 
 template <int BITS>
 int launch_multi_bits(const GemvMultiParams& p, hipStream_t stream) {
   constexpr int UBMAX = max_ub<BITS>();
-  if (p.m != 1 || p.groupsize % (32u * UBMAX) != 0) return XBIT_ERR_SHAPE;  // caller launches one by one
+  if (p.m > 4 || p.groupsize % (32u * UBMAX) != 0) return XBIT_ERR_SHAPE;  // caller launches one by one
   uint32_t total_n = 0;
   for (uint32_t j = 0; j < p.multi_count; ++j) total_n += p.multi_n[j];
   const int cpl = pick_cpl(total_n);  // the width the concatenated layer would get

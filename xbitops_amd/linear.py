@@ -63,7 +63,7 @@ class QuantLinear(torch.nn.Module):
 class QuantLinearGroup(torch.nn.Module):
     """Several :class:`QuantLinear` layers that read the SAME input (q/k/v, gate/up).
 
-    ``forward(x)`` returns the list of their outputs.  A single token (one row) goes through
+    ``forward(x)`` returns the list of their outputs.  Up to four rows (a decode step, a short speculative batch) go through
     ``ops.gemv_multi`` - one kernel launch for the whole group instead of one per layer, which is what
     the small layers of a decoder need (they sit on the launch floor); anything else runs the layers
     one by one.  The layers must share ``in_features``, ``bits``, ``groupsize`` and ``add_zero_bias``.
@@ -84,7 +84,7 @@ class QuantLinearGroup(torch.nn.Module):
         first = self.layers[0]
         lead = x.shape[:-1]
         x2 = x.reshape(-1, first.in_features)
-        if x2.shape[0] != 1:
+        if not 1 <= x2.shape[0] <= 4:  # the fused launch takes up to 4 rows
             return [layer(x) for layer in self.layers]
         x2 = x2.to(torch.float16).contiguous()
         ys = ops.gemv_multi(x2, [(layer.qweight, layer.scales, layer.qzeros) for layer in self.layers], first.groupsize, first.bits,
