@@ -12,7 +12,7 @@ from xbitops_amd import _lib, synth  # noqa: E402
 
 
 def main():
-    variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "12,13,15,21,22,28,39,105,51,53,55,56").split(",")]
+    variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "12,13,15,21,22,28,39,105,51,53,55,56,64").split(",")]
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     raw = ctypes.CDLL(_lib.LIB_PATH)

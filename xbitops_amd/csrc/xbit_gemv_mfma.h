@@ -95,6 +95,7 @@ struct RowLoad {
 //   ABLATE (measurement builds only): 1 = no weight loads (registers stand in), 2 = no
 //          unpack/dequant/MFMA (loaded words are xor-folded), 3 = both (all three: wrong results);
 //          4 = correct results, always the spliced (pre-subnormal) unpack, for A/B timing;
+//          16 = correct results (M = 1), multiply-accumulate on the VALU (v_dot2_f32_f16 + shuffles) instead of the MFMA;
 //          8 = correct results plus per-wave s_memrealtime stamps written to p.trace
 //   LA   load lookahead in row loads (0 = issue the whole batch up front).  A wave issues in order,
 //        and the CU's memory pipeline back-pressures: a wave that queues all its loads first sits at
@@ -390,9 +391,16 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
               for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]));
             }
           });
+          if constexpr (ABLATE & 16) {  // measurement: the same W pairs accumulated on the VALU (v_dot2_f32_f16), M = 1
 #pragma unroll
-          for (int c = 0; c < CPL; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) acc[c][0] = __builtin_amdgcn_fdot2(as_h2(braw[c][e]), as_h2(araw[e]), acc[c][0], false);
+          } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+          }
         }
         if constexpr (LA > 0) __builtin_amdgcn_sched_barrier(0);
       });
@@ -408,6 +416,18 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  if constexpr (ABLATE & 16) {
+    // VALU build: sum the four k-slot lane groups by shuffles, then present the result where the
+    // MFMA build has it (row 0 of the D tile = register 0 of lanes 0-15)
+    static_assert(!(ABLATE & 16) || (NL == 16 && MT == 1), "VALU measurement build");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      float v = acc[c][0];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[c][0] = v;
+    }
+  }
   if constexpr (ALIAS) __syncthreads();  // every wave is done reading its activations
   // D[drow][slot]: drow = 4*(lane>>4) + r lives in register r of lane (lane>>4, slot = lane&15).
   // Keep the quadrant where the row block equals the slot's k-slot, then sum over k-slots and waves.
@@ -733,6 +753,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
           case 46: return launch_la<BITS, 4, 4, 16, 8, 1, kLookahead>(p, stream);
           case 47: return launch_la<BITS, 4, 4, 16, 8, 2, kLookahead>(p, stream);
           case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);  // stamped (tools/gemv_trace.py)
+          case 64: return launch_la<BITS, 4, 3, 16, 8, 16, kLookahead>(p, stream);  // VALU accumulate (v_dot2) instead of MFMA
           default: break;
         }
       }
