@@ -523,3 +523,38 @@ def test_gemv_multi_fused_launch(bits, cuda_device):
             assert_gemv_close(y.cpu().numpy(), single.cpu().numpy().astype(np.float16), "multi vs single")
     with pytest.raises(RuntimeError):
         ops.gemv_multi(a, [], 128, bits, k, 1)
+
+
+def test_split_k_overflow_and_nan_follow_the_unsplit_result(cuda_device):
+    """Split-K accumulates in fixed point; partial sums outside its range, Inf and NaN must still give
+    what the unsplit kernel stores: +Inf / -Inf on overflow, NaN for NaN (or Inf - Inf)."""
+    import ctypes
+
+    import XbitOps
+    from xbitops_amd import _lib
+
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
+    k, n = 16384, 256
+    p = synth.make_problem(k, n, 4, 128, m=1, seed=321)
+    act = p.act.copy()
+    sc = p.scales.astype(np.float32)
+    sc[:, 0:64] = 200.0     # columns 0-63: huge positive/negative sums -> +-Inf in fp16
+    p.scales = sc.astype(np.float16)
+    a, qw, scd, qz = (torch.from_numpy(x).to(cuda_device) for x in (act, p.qweight, p.scales, p.qzeros))
+    try:
+        raw.xbit_debug_set_gemv_split(1)
+        want = XbitOps.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
+        raw.xbit_debug_set_gemv_split(0)
+        got = XbitOps.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
+        big = ~np.isfinite(want)
+        assert big[:, :64].any()                       # the test does overflow
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(got[big & ~np.isnan(want)], want[big & ~np.isnan(want)])   # same signed infinities
+        assert_gemv_close(got[~big], want[~big], "finite columns")
+        act[0, 7] = np.float16(np.nan)                 # a NaN activation poisons every output
+        a = torch.from_numpy(act).to(cuda_device)
+        got = XbitOps.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
+        assert np.isnan(got).all()
+    finally:
+        raw.xbit_debug_set_gemv_split(0)

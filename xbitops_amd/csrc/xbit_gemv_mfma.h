@@ -460,19 +460,24 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       // to stay positive) by a returning atomic whose upper bits count the arrivals.  Integer
       // addition is associative, so the total does not depend on the arrival order; 2^-28 is below
       // half the smallest fp16 spacing.  The thread that completes the count converts and stores,
-      // then clears the slot for the next launch.  Layout: bits 0-55 sum of (v + 2^51), 56-59
-      // arrivals, 60-63 arrivals whose partial sum was not finite / out of range (-> NaN).
+      // then clears the slot for the next launch.  Layout: bits 0-51 sum of (v + 2^47), 52-55
+      // arrivals, 56-59 arrivals with a partial sum >= 2^19 or +Inf, 60-63 with one <= -2^19 or -Inf
+      // (a NaN counts in both): the result is then +Inf, -Inf or, with both kinds present, NaN - what
+      // an fp16 store of the unsplit sum would give (65504 is the largest finite fp16).
       if (valid) {
         unsigned long long* slot = p.acc + ((size_t)blockIdx.y * p.tiles + tile_g) * (size_t)(MT * CN) + e;
-        const bool fin = __builtin_fabsf(sum) < 8388608.0f;  // 2^23; false for NaN / Inf too
-        const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;  // |v| < 2^51
-        const unsigned long long add = (unsigned long long)(v + (1ll << 51)) + (1ull << 56) + (fin ? 0ull : (1ull << 60));
+        const bool fin = __builtin_fabsf(sum) < 524288.0f;  // 2^19; false for NaN / Inf too
+        const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;  // |v| < 2^47
+        const unsigned long long pos = (!fin && !(sum < 0.f)) ? (1ull << 56) : 0ull;  // +huge, +Inf, NaN
+        const unsigned long long neg = (!fin && !(sum > 0.f)) ? (1ull << 60) : 0ull;  // -huge, -Inf, NaN
+        const unsigned long long add = (unsigned long long)(v + (1ll << 47)) + (1ull << 52) + pos + neg;
         const unsigned long long old = __hip_atomic_fetch_add(slot, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (((old >> 56) & 15ull) + 1ull == p.splits) {
+        if (((old >> 52) & 15ull) + 1ull == p.splits) {
           const unsigned long long tot = old + add;
-          const long long fixed = (long long)(tot & ((1ull << 56) - 1ull)) - (long long)p.splits * (1ll << 51);
+          const long long fixed = (long long)(tot & ((1ull << 52) - 1ull)) - (long long)p.splits * (1ll << 47);
           float y = (float)fixed * (1.0f / 268435456.0f);
-          if (tot >> 60) y = __builtin_nanf("");
+          const bool any_pos = ((tot >> 56) & 15ull) != 0, any_neg = (tot >> 60) != 0;
+          if (any_pos || any_neg) y = (any_pos && any_neg) ? __builtin_nanf("") : (any_pos ? __builtin_inff() : -__builtin_inff());
           out_[(size_t)row * n_ + n_out] = as_u16((_Float16)y);
           __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
