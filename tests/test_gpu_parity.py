@@ -10,6 +10,8 @@ Gates:
   accumulated in fp32, the observed error is a few fp32 ulps plus the final fp16 rounding.
 """
 import glob
+import hashlib
+import json
 import os
 
 import numpy as np
@@ -23,6 +25,8 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIXTURES = sorted(glob.glob(os.path.join(GOLD, "dq_b*.npz")))
+with open(os.path.join(GOLD, "digests.json")) as _f:
+    DIGESTS = json.load(_f)
 
 
 def _bits(x):
@@ -186,6 +190,86 @@ def test_gemv_w4_llama7b_ffn_full_size(cuda_device):
     y = run_gemv(p, 1, cuda_device)
     y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, 4096, 1, oracle.RNE)
     assert_gemv_close(y, y_ref, "cfg2")
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_gemv_bit_sweep_4096x4096_full_size(bits, cuda_device):
+    """BASELINE.json configs 1 and 3 at their stated size: in=4096 out=4096 g128 batch 1, b = 2..8 (256
+    tiles of 16 columns / the launch shape the real layer gets, not a narrow stand-in)."""
+    p = synth.make_problem(4096, 4096, bits, 128, m=1, seed=300 + bits)
+    for bias in (0, 1):
+        y = run_gemv(p, bias, cuda_device)
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, 4096, bias, oracle.RNE)
+        assert_gemv_close(y, y_ref, "cfg3 bits=%d bias=%d" % (bits, bias))
+
+
+@pytest.mark.parametrize("m", [1, 4, 16])
+def test_gemv_w3_skinny_4096x11008_full_size(m, cuda_device):
+    """BASELINE.json config 5 at its stated size: A16W3 in=4096 out=11008 g128, batch 1 / 4 / 16
+    (the 8-wave whole-K launch with 1, 4 and 16 rows per pass)."""
+    p = synth.make_problem(4096, 11008, 3, 128, m=m, seed=500 + m)
+    y = run_gemv(p, 1, cuda_device)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 3, 4096, 1, oracle.RNE)
+    assert_gemv_close(y, y_ref, "cfg5 m=%d" % m)
+
+
+@pytest.mark.parametrize("m", [4, 16])
+def test_gemv_w4_skinny_4096x11008_full_size(m, cuda_device):
+    """The metric shape at batch 4 and 16 (skinny-GEMM edge of the headline bit-width)."""
+    p = synth.make_problem(4096, 11008, 4, 128, m=m, seed=600 + m)
+    y = run_gemv(p, 1, cuda_device)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, 4096, 1, oracle.RNE)
+    assert_gemv_close(y, y_ref, "w4 4096x11008 m=%d" % m)
+
+
+@pytest.mark.parametrize("name", sorted(DIGESTS))
+def test_dequant_full_size_digest_shapes(name, cuda_device):
+    """The nine full-size shapes whose reference-simulator output is pinned by SHA-256
+    (tests/golden/digests.json, oracle/gen_golden.py): the HIP dequant is bit-exact against the
+    oracle in hardware rounding (RNE), the oracle in simulator rounding reproduces the pinned digest
+    on the same inputs, and the two stay within the reference's own 1e-3 tolerance
+    (unpack_weight_2_to_7.cu:570)."""
+    d = DIGESTS[name]
+    k, n, bits, g = d["k"], d["n"], d["bits"], d["groupsize"]
+    p = synth.make_problem(k, n, bits, g, m=1, seed=d["seed"])
+    w = run_dequant(p, 0, cuda_device)
+    w_rne = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, 0, oracle.RNE)
+    assert np.array_equal(_bits(w), _bits(w_rne)), name
+    w_sim = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, 0, oracle.SIM)
+    assert hashlib.sha256(np.ascontiguousarray(w_sim).tobytes()).hexdigest() == d["sha256_w_ref"], name
+    assert np.abs(w.astype(np.float32) - w_sim.astype(np.float32)).max() <= 1e-3, name
+
+
+def test_mfma_and_valu_accumulate_builds_agree(cuda_device):
+    """DESIGN.md's A/B of the north star's "no MFMA" design: the measurement build that accumulates
+    on the VALU (v_dot2_f32_f16 + shuffles, variant 64) must give the production (MFMA) kernel's
+    result up to the fp32 summation order, and both must meet the oracle."""
+    import ctypes
+
+    import XbitOps
+    from xbitops_amd import _lib
+
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    if not hasattr(raw, "xbit_debug_set_gemv_variant"):
+        pytest.skip("library built without the measurement variants (XBIT_TUNING=0)")
+    raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
+    try:
+        for k, n in ((4096, 11008), (4096, 1008), (2048, 512)):
+            p = synth.make_problem(k, n, 4, 128, m=1, seed=64 + n)
+            a, qw, sc, qz = to_dev(p, cuda_device)
+            y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+            raw.xbit_debug_set_gemv_variant(-1)
+            y_mfma = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+            raw.xbit_debug_set_gemv_variant(64)
+            y_valu = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+            torch.cuda.synchronize()
+            assert_gemv_close(y_mfma.cpu().numpy(), y_ref, "mfma k=%d n=%d" % (k, n))
+            assert_gemv_close(y_valu.cpu().numpy(), y_ref, "valu k=%d n=%d" % (k, n))
+            d = (y_mfma.view(torch.int16).int() - y_valu.view(torch.int16).int()).abs()
+            close = (d <= 1) | ((y_mfma.float() - y_valu.float()).abs() <= 4e-6)  # last fp16 bit, or fp32 noise where the sum cancels
+            assert bool(close.all()) and float((d == 0).float().mean()) > 0.98
+    finally:
+        raw.xbit_debug_set_gemv_variant(-1)
 
 
 def test_gemv_linearity_full_size(cuda_device):

@@ -23,21 +23,43 @@ def test_quantize_pack_round_trip(bits, bias):
     assert np.abs(w_deq - recon).max() <= 2e-3 * np.abs(recon).max() + 1e-4  # fp16 rounding of the same value
 
 
+def _oracle_forward(layer, x):
+    """oracle GEMV on the module's own packed buffers (copied to the host): the independent checker."""
+    qw, sc, qz = (t.detach().cpu().numpy() for t in (layer.qweight, layer.scales, layer.qzeros))
+    a = x.detach().reshape(-1, layer.in_features).cpu().numpy()
+    return oracle.gemv(a, qw, sc, qz, layer.groupsize, layer.bits, layer.in_features, layer.add_zero_bias, oracle.RNE)
+
+
+def _assert_close_to_oracle(y, y_ref, what):
+    yf, rf = y.detach().float().cpu().numpy().astype(np.float64), y_ref.astype(np.float64)
+    assert yf.shape == rf.shape, what
+    assert (np.abs(yf - rf) <= 1e-3 * np.abs(rf) + 2.0 ** -14).all(), what
+
+
 @pytest.mark.gpu
-def test_quant_linear_forward(cuda_device):
+@pytest.mark.parametrize("bits,bias", [(4, 1), (3, 0), (8, 1)])
+def test_quant_linear_forward(bits, bias, cuda_device):
     from xbitops_amd.linear import QuantLinear
 
-    torch.manual_seed(0)
+    torch.manual_seed(bits)
     w = torch.randn(512, 128) * 0.05
-    layer = QuantLinear.from_float(w, bits=4, groupsize=128, add_zero_bias=1).to(cuda_device)
-    w_deq = layer.dequantize().float()
-    assert (w_deq.cpu() - w).abs().max() < 0.05
-    for rows in (1, 5, 40):  # GEMV path, skinny path, dequant + GEMM path
+    layer = QuantLinear.from_float(w, bits=bits, groupsize=128, add_zero_bias=bias).to(cuda_device)
+    qw, sc, qz = (t.cpu().numpy() for t in (layer.qweight, layer.scales, layer.qzeros))
+    w_ref = oracle.dequant(qw, sc, qz, 128, bits, 512, bias, oracle.RNE)
+    w_deq = layer.dequantize()
+    assert np.array_equal(w_deq.cpu().numpy().view(np.uint16), w_ref.view(np.uint16))  # bit-exact vs the oracle
+    assert (w_deq.float().cpu() - w).abs().max() < (0.05 if bits >= 4 else 0.12)
+    for rows in (1, 5, 16):  # GEMV path (1, 8- and 16-row passes): the oracle GEMV on the same packed buffers
         x = (torch.randn(rows, 512, device=cuda_device) * 0.5).half()
         y = layer(x)
-        y_ref = x.float() @ w_deq
         assert y.shape == (rows, 128)
-        assert (y.float() - y_ref).abs().max() <= 2e-3 * y_ref.abs().max() + 1e-3
+        _assert_close_to_oracle(y, _oracle_forward(layer, x), "bits=%d rows=%d" % (bits, rows))
+    # dequant + dense GEMM path (> 16 rows): fp16 GEMM of the oracle's W, fp32 accumulation order unknown
+    x = (torch.randn(40, 512, device=cuda_device) * 0.5).half()
+    y = layer(x)
+    y_ref = oracle.matvec_f16(x.cpu().numpy(), w_ref).astype(np.float64)
+    assert y.shape == (40, 128)
+    assert (np.abs(y.float().cpu().numpy() - y_ref) <= 2e-3 * np.abs(y_ref) + 1e-3).all()
     assert layer(torch.zeros(2, 3, 512, device=cuda_device).half()).shape == (2, 3, 128)
 
 
@@ -53,6 +75,7 @@ def test_gemv_plan_equals_gemv(cuda_device):
     a, qw, sc, qz = (torch.from_numpy(x).to(cuda_device) for x in (p.act, p.qweight, p.scales, p.qzeros))
     plan = ops.GemvPlan(qw, sc, qz, 128, 4, 1024, 1)
     assert torch.equal(plan(a), XbitOps.gemv(a, qw, sc, qz, 128, 4, 1024, 1))
+    _assert_close_to_oracle(plan(a), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, 1024, 1, oracle.RNE), "GemvPlan")
     a3 = a.reshape(1, 3, 1024)
     assert torch.equal(plan(a3), XbitOps.gemv(a3, qw, sc, qz, 128, 4, 1024, 1))
     with pytest.raises(RuntimeError):
@@ -83,7 +106,8 @@ def test_quant_linear_group(cuda_device):
         ys = group(x)
         assert len(ys) == 3
         for layer, y in zip(layers, ys):
-            want = layer(x)
+            _assert_close_to_oracle(y, _oracle_forward(layer, x), "group rows=%d n=%d" % (rows, layer.out_features))  # the checker
+            want = layer(x)  # and the layer on its own: same kernel family, agreement to the last fp16 bit
             assert y.shape == want.shape
             assert (y.float() - want.float()).abs().max() <= 1e-3 * want.float().abs().max() + 2.0 ** -14
     with pytest.raises(ValueError):

@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       for (int q = 0; q < CPT; ++q) {
         uint32_t o = aoff + 16u * q;
         if (GUARD && CPT > 1 && k0 + 8u * q >= k_end) o = kOob;
-        hraw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
+        if constexpr (ABLATE & 32) hraw[r][q] = u32x4_t{o, o + 1u, o + 2u, o + 3u};  // measurement: no activation loads
+        else hraw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
       }
     }
 
@@ -237,7 +238,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       const uint32_t h0 = gi * n_ + col;
       uint32_t soff = (h0 & ~1u) * 2u;
       if (GUARD && !active) soff = kOob;
-      if constexpr (CPL == 2) {  // col and n are even: h0 is even
+      if constexpr (ABLATE & 64) {  // measurement: no scale loads
+        sbits[0] = 0x1C00u + (soff & 0xFFu);
+        sbits[1] = sbits[0] + 1u;
+        if constexpr (CPL > 2) sbits[2] = sbits[0] + 2u;
+        if constexpr (CPL > 3) sbits[3] = sbits[0] + 3u;
+      } else if constexpr (CPL == 2) {  // col and n are even: h0 is even
         const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r_s, soff, 0, 0);
         sbits[0] = v & 0xFFFFu;
         sbits[1] = v >> 16;
@@ -255,7 +261,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     {
       const uint32_t bit = col * BITS, sh = bit & 31u;
       const uint32_t zoff = (gi * zw_ + (bit >> 5)) * 4u;
-      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
+      if constexpr (ABLATE & 64) {
+        zwin = zoff >> sh;  // measurement: no zero-point loads
+      } else if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
         zwin = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0) >> sh;  // the CPL fields never straddle a word
       } else {
         const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_z, zoff, 0, 0);  // a read past the row end is harmless
@@ -319,7 +327,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
                                ((uint32_t)(4 + 2 * (khi & 1)) << 16) | ((uint32_t)(5 + 2 * (khi & 1)) << 24);
           o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
         }
-        *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
+        if constexpr (!(ABLATE & 32)) *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
+        else asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
       }
     }
     // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
@@ -427,6 +436,13 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       v += __shfl_xor(v, 32, 64);
       acc[c][0] = v;
     }
+  }
+  if constexpr (ABLATE & 128) {  // measurement: no cross-wave reduction, every lane stores something
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) v += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    if (col_ok) out_[(tile * CN + (uint32_t)(tid % CN)) % n_] = as_u16((_Float16)v);
+    return;
   }
   if constexpr (ALIAS) __syncthreads();  // every wave is done reading its activations
   // D[drow][slot]: drow = 4*(lane>>4) + r lives in register r of lane (lane>>4, slot = lane&15).
@@ -759,6 +775,28 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
           case 47: return launch_la<BITS, 4, 4, 16, 8, 2, kLookahead>(p, stream);
           case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);  // stamped (tools/gemv_trace.py)
           case 64: return launch_la<BITS, 4, 3, 16, 8, 16, kLookahead>(p, stream);  // VALU accumulate (v_dot2) instead of MFMA
+          // round-2 experiments: loads-only builds at other lookaheads, full builds at LA 5 / 12, 16 waves at deeper LA
+          case 131: return launch_la<BITS, 4, 3, 16, 8, 2, 0>(p, stream);
+          case 150: return launch_la<BITS, 4, 3, 16, 8, 2 | 32, 4>(p, stream);              // loads only, no activation staging
+          case 151: return launch_la<BITS, 4, 3, 16, 8, 2 | 64, 4>(p, stream);              // loads only, no scale / zero loads
+          case 152: return launch_la<BITS, 4, 3, 16, 8, 2 | 128, 4>(p, stream);             // loads only, no LDS reduction
+          case 153: return launch_la<BITS, 4, 3, 16, 8, 2 | 32 | 64 | 128, 4>(p, stream);   // loads only, none of the three
+          case 154: return launch_la<BITS, 4, 3, 16, 8, 2 | 32 | 64 | 128, 0>(p, stream);   // ... all loads up front
+          case 155: return launch_la<BITS, 4, 3, 16, 8, 32 | 64 | 128, 4>(p, stream);       // arithmetic kept, none of the three
+          case 156: return launch_la<BITS, 4, 3, 16, 8, 128, 4>(p, stream);                 // full kernel minus the LDS reduction
+          case 157: return launch_la<BITS, 4, 3, 16, 8, 32, 4>(p, stream);                  // full kernel minus activation staging
+          case 158: return launch_la<BITS, 4, 3, 16, 8, 64, 4>(p, stream);                  // full kernel minus scale / zero loads
+          case 132: return launch_la<BITS, 4, 3, 16, 8, 2, 6>(p, stream);
+          case 133: return launch_la<BITS, 4, 3, 16, 8, 2, 8>(p, stream);
+          case 134: return launch_la<BITS, 4, 3, 16, 8, 2, 12>(p, stream);
+          case 135: return launch_m1<BITS, 4, 3, 16, 8, false, 5>(p, stream);
+          case 136: return launch_m1<BITS, 4, 4, 16, 8, false, 6>(p, stream);
+          case 137: return launch_m1<BITS, 4, 4, 16, 8, false, 2>(p, stream);
+          case 138: return launch_m1<BITS, 2, 3, 16, 16, false, 4>(p, stream);   // 16 waves x 2 k-blocks
+          case 139: return launch_m1<BITS, 2, 3, 16, 16, false, 7>(p, stream);   // ... all 8 loads of a wave up front
+          case 140: return launch_m1<BITS, 2, 3, 16, 16, false, 2>(p, stream);
+          case 141: return launch_la<BITS, 2, 3, 16, 16, 2, 7>(p, stream);       // ... loads only
+          case 142: return launch_la<BITS, 2, 3, 16, 16, 2, 4>(p, stream);
           default: break;
         }
       }
