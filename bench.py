@@ -1,34 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — A16W4 GEMV throughput on MI355X, the metric BASELINE.json names.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg4] [--shape K,N,bits,g,M]
 
-One "step" = one call of the hot path (xbit_gemv_f16 through the C ABI) on the Llama-7B FFN
-shape of BASELINE.json config 2: in=4096, out=11008, 4-bit, group 128, batch 1, synthetic data
-(xbitops_amd.synth).  The step rotates over enough distinct weight copies (>= 512 MB in total,
-twice the 256 MB Infinity Cache) that every launch streams its weights from HBM ("cold");
-a cache-resident ("warm") figure is reported beside it, never as the headline.
+One "step" = one call of the hot path (xbit_gemv_f16 through the C ABI) plus, on N > 1 GPUs, the ONE
+all-gather of the fp16 output shards that a column-sharded layer needs before its result can be
+used (issued per step on the compute stream: no bucketing, a decoder cannot defer it).
 
-Printed JSON (one line, rank 0):
-  value / ms_per_step  whole-job GB/s of algorithmic bytes and wall time per step over exactly K
-                       steps between barrier+synchronize pairs.  The K launches are replayed from a
-                       hipGraph so the host is not the bottleneck; kernel-to-kernel boundaries ARE
-                       included.
-  roofline             algorithmic bytes per launch / average KERNEL duration, measured live with
-                       HIP events that bracket each launch on its own stream
-                       (hipExtLaunchKernel start/stop events via xbit_profile_enable), cold weights.
-                       peak = 8000 GB/s (HBM3E spec, MI355X_MICROARCH.md).  `traffic` is filled from
-                       rocprofv3 PMC runs offline (profiles/), null here.
-  cpu_baseline         the oracle's C restatement (fused dequant + GEMV, OpenMP) timed on this
-                       box's host cores on repeated full-size GEMVs for ~10 s.  Reported, not a target.
-N > 1 (launched by torch.distributed.run): weak scaling — every rank owns one 4096x11008 column
-shard of a 4096 x (11008*N) layer, no data-path collective inside the GEMV; the fp16 output
-shards are all-gathered over RCCL on a side stream, bucketed, overlapping the following GEMVs.
+Workloads
+  cfg2 (default)  BASELINE.json configs[1]: in=4096 out=11008 4-bit g128 batch 1 per GPU (Llama-7B
+                  FFN).  N > 1: weak scaling, every rank owns one 4096x11008 column shard of a
+                  4096 x (11008*N) layer.
+  cfg4            BASELINE.json configs[3]: in=8192 out=28672 (Llama-70B FFN) column-sharded N ways
+                  with xbitops_amd.sharded.shard_columns — strong scaling; N = 1 is the whole layer.
+  --shape         any other K,N,bits,group,M on one GPU (used to profile configs 3 and 5).
+Weights rotate over enough distinct copies (>= 512 MB in total, twice the 256 MB Infinity Cache) that
+every timed launch streams from HBM ("cold").
+
+Printed JSON (one line, rank 0)
+  value / ms_per_step  algorithmic bytes of all ranks x K / the time of exactly K steps, measured with
+                       HIP events recorded ON THE COMPUTE STREAM around the region,
+                       max over ranks, between barrier + synchronize pairs.  On one GPU the K
+                       launches are queued behind a blocker kernel that outlasts the host's enqueue time,
+                       so the span holds device time only: K x (kernel + launch boundary,
+                       `boundary_us_per_step`); `host_clock_ms_per_step` is the host's view (blocker included).
+  roofline             algorithmic bytes per launch / mean KERNEL duration over >= 200 cold launches
+                       (whatever --steps says), each bracketed by HIP events on its own stream
+                       (hipExtLaunchKernel via xbit_profile_enable).  peak = 8000 GB/s (HBM3E spec).
+                       `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/
+                       when they were taken from THIS build of the library (sha256 match), else null.
+  cpu_baseline         (N = 1) the oracle's C restatement (fused dequant + GEMV, OpenMP) for ~10 s, and
+                       the torch-CPU path (int32 shift/mask unpack -> fp16 W -> a @ W) timed as
+                       unpack + matmul and matmul alone, thread counts stated.  Reported, not a target.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -38,37 +47,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-K_IN, N_OUT, BITS, GROUP, BATCH = 4096, 11008, 4, 128, 1
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 COLD_BYTES = 512 << 20
+MIN_ROOFLINE_LAUNCHES = 200
+CONFIGS = {
+    # name: (K, N, bits, group, M, scaling, workload text)
+    "cfg2": (4096, 11008, 4, 128, 1, "weak", "A16W4 GEMV in=4096 out=11008 group=128 batch=1 (Llama-7B FFN, BASELINE.json configs[1]) per GPU"),
+    "cfg4": (8192, 28672, 4, 128, 1, "strong", "A16W4 GEMV in=8192 out=28672 group=128 batch=1 (Llama-70B FFN, BASELINE.json configs[3]) column-sharded over the GPUs"),
+}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--shape", default="", help="K,N,bits,group,M: another single-GPU workload (profiling configs 3 and 5)")
+    ap.add_argument("--graph", action="store_true", help="one GPU: time a hipGraph replay of the K launches instead of queued eager launches")
+    ap.add_argument("--no-graph", action="store_true", help="accepted for compatibility (eager launches are the default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--gather-bucket", type=int, default=32, help="N>1: steps per all-gather bucket")
-    ap.add_argument("--variant", type=int, default=-1, help="tuning: GEMV launch-shape variant")
-    return ap.parse_args()
+    ap.add_argument("--roofline-launches", type=int, default=MIN_ROOFLINE_LAUNCHES, help="event-bracketed cold launches (at least 200)")
+    ap.add_argument("--warm", action="store_true", help="also report the cache-resident kernel time (one weight copy)")
+    ap.add_argument("--variant", type=int, default=-1, help="tuning builds only: GEMV launch-shape variant")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(seconds: float, nbytes: int):
-    """Oracle C restatement (kind 'port'), fused dequant+GEMV, OpenMP over output columns."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, one GPU).  The oracle may be used here and only here (it is the thing timed).
+def cpu_baseline_port(seconds: float, k: int, n: int, bits: int, g: int, m: int, nbytes: int):
     import numpy as np
 
     import oracle
     from xbitops_amd import synth
 
     oracle.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box grants a 16-CPU share per GPU
-    p = synth.make_problem(K_IN, N_OUT, BITS, GROUP, m=BATCH, seed=7)
-    oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, GROUP, BITS, K_IN, 1)  # warm (page in, spin up threads)
+    p = synth.make_problem(k, n, bits, g, m=m, seed=7)
+    oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1)  # warm (page in, spin up threads)
     reps, t0 = 0, time.perf_counter()
     while True:
-        y = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, GROUP, BITS, K_IN, 1)
+        y = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1)
         reps += 1
         dt = time.perf_counter() - t0
         if dt >= seconds and reps >= 3:
@@ -76,53 +95,100 @@ def cpu_baseline(seconds: float, nbytes: int):
     assert np.isfinite(y.astype(np.float32)).all()
     return {
         "value": round(nbytes * reps / dt / 1e9, 4), "unit": "GB/s", "cores": oracle.num_threads(), "kind": "port",
-        "sample": "%d full-size %dx%d w%d g%d batch-%d GEMVs in %.1f s (oracle/xbit_oracle.c xo_gemv, OpenMP; host has %d logical CPUs)"
-                  % (reps, K_IN, N_OUT, BITS, GROUP, BATCH, dt, os.cpu_count()),
+        "sample": "%d full-size %dx%d w%d g%d batch-%d GEMVs in %.1f s (oracle/xbit_oracle.c xo_gemv, fused dequant + GEMV, OpenMP; host has %d logical CPUs)"
+                  % (reps, k, n, bits, g, m, dt, os.cpu_count()),
         "ms_per_gemv": round(1e3 * dt / reps, 3),
+    }, p, y
+
+
+def torch_cpu_unpack(qweight, scales, qzeros, bits: int, g: int, k: int, add_zero_bias: int):
+    """The plumbing path of BASELINE.json config 1 in stock torch on the CPU: int32 shift/mask unpack of
+    the LSB-first bit-streams -> fp16 W = q*s - (z + bias)*s (each product rounded to fp16)."""
+    import torch
+
+    kw, n = qweight.shape
+    mask = (1 << bits) - 1
+    kk = torch.arange(k, dtype=torch.int64)
+    bit = kk * bits
+    wi, sh = bit >> 5, (bit & 31).to(torch.int32)
+    qw64 = qweight.to(torch.int64) & 0xFFFFFFFF
+    lo = qw64[wi] >> sh.to(torch.int64)[:, None]
+    hi_rows = torch.clamp(wi + 1, max=kw - 1)
+    hi = qw64[hi_rows] << (32 - sh.to(torch.int64))[:, None]
+    q = ((lo | hi) & mask).to(torch.float16)  # [K, N]
+    nn = torch.arange(n, dtype=torch.int64)
+    zbit = nn * bits
+    zi, zs = zbit >> 5, zbit & 31
+    qz64 = qzeros.to(torch.int64) & 0xFFFFFFFF
+    zlo = qz64[:, zi] >> zs[None, :]
+    zhi = qz64[:, torch.clamp(zi + 1, max=qzeros.shape[1] - 1)] << (32 - zs)[None, :]
+    z = (((zlo | zhi) & mask) + add_zero_bias).to(torch.float16)  # [G, N]
+    zsc = z * scales  # fp16 product, rounded (hmul)
+    gi = kk // g
+    return q * scales[gi] - zsc[gi]  # two roundings here (mul, sub) where the kernels fuse: a CPU baseline, not the checker
+
+
+def cpu_baseline_torch(p, y_port, bits: int, g: int, k: int, nbytes: int, budget_s: float):
+    import numpy as np
+    import torch
+
+    qw, sc, qz = torch.from_numpy(p.qweight), torch.from_numpy(p.scales), torch.from_numpy(p.qzeros)
+    a = torch.from_numpy(p.act)
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    w = torch_cpu_unpack(qw, sc, qz, bits, g, k, 1)
+    t_unpack = time.perf_counter() - t0
+    (a @ w)  # warm
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < min(2.0, budget_s) and reps < 200):
+        y = a @ w
+        reps += 1
+    t_mm = (time.perf_counter() - t0) / reps
+    ref = y_port.astype(np.float32)
+    err = np.abs(y.float().numpy() - ref)
+    assert (err <= 5e-3 * np.abs(ref) + 2e-3).all(), "torch-CPU fallback disagrees with the C restatement"  # fp16 GEMM + unfused W
+    return {
+        "threads": threads, "unpack_ms": round(1e3 * t_unpack, 2), "matmul_only_ms": round(1e3 * t_mm, 3),
+        "unpack_plus_matmul_ms": round(1e3 * (t_unpack + t_mm), 2),
+        "gbps_unpack_plus_matmul": round(nbytes / (t_unpack + t_mm) / 1e9, 4),
+        "gbps_matmul_only_fp16_weights": round((2 * w.numel() + 2 * a.numel() + 2 * y.numel()) / t_mm / 1e9, 3),
+        "what": "stock torch %s on the host: int32 shift/mask unpack -> fp16 W (once), then a.half() @ W averaged over %d calls" % (torch.__version__, reps),
     }
 
 
-def pmc_traffic(workload_key: str):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE with
-    the gfx950 x2 correction + WRITE_SIZE; collected offline — counters cannot be read in-process).
-    Returns None when no record matches this workload."""
+# ------------------------------------------------------------------------------------------------
+def lib_sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def offline_profile(workload_key: str, this_lib_sha: str):
+    """rocprofv3 numbers committed under profiles/rNN/ for this workload (collected offline: counters
+    cannot be read in-process).  `matches_this_build` says whether they were taken from the library
+    that is running now; only then do they appear in `roofline`."""
     best = None
-    for root, _dirs, files in os.walk(os.path.join(ROOT, "profiles")):
-        if "pmc_traffic.json" in files:
-            try:
-                with open(os.path.join(root, "pmc_traffic.json")) as f:
-                    rec = json.load(f)
-                if rec.get("workload") == workload_key:
-                    best = (os.path.relpath(os.path.join(root, "pmc_traffic.json"), ROOT), rec)
-            except (OSError, ValueError):
-                pass
+    prof = os.path.join(ROOT, "profiles")
+    for rnd in sorted(d for d in (os.listdir(prof) if os.path.isdir(prof) else []) if d.startswith("r")):
+        path = os.path.join(prof, rnd, "pmc_traffic.json")
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload_key:
+            best = dict(rec, source=os.path.relpath(path, ROOT), matches_this_build=rec.get("lib_sha256") == this_lib_sha)
     return best
 
 
-def rocprof_kernel_avg_us():
-    """Average duration of the GEMV kernel in the committed rocprofv3 --kernel-trace --stats summary
-    of this same command (profiles/rNN/bench_kernel_stats.csv, newest round), for comparison with
-    the live HIP-event figure.  None when there is no summary."""
-    import csv
-    import glob
-
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_kernel_stats.csv")), reverse=True):
-        try:
-            with open(path) as f:
-                for row in csv.DictReader(f):
-                    if "gemv_mfma_kernel" in row["Name"]:
-                        return os.path.relpath(path, ROOT), round(float(row["AverageNs"]) / 1e3, 3)
-        except (OSError, ValueError, KeyError):
-            pass
-    return None
-
-
-def main():
-    args = parse_args()
+def main(argv=None):
+    args = parse_args(argv)
     import torch
     import torch.distributed as dist
 
-    from xbitops_amd import _lib, synth
+    from xbitops_amd import _lib, sharded, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +202,7 @@ def main():
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for the 1-GPU rehearsal below
     torch.cuda.set_device(dev)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # nccl == RCCL on ROCm.  XBIT_BENCH_BACKEND=gloo rehearses the multi-rank control flow with
@@ -147,133 +214,162 @@ def main():
             dist.init_process_group(backend)
 
     lib = _lib.load()  # raises if the HIP library is missing
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
-    raw.xbit_debug_set_gemv_variant(args.variant)
+    if args.variant >= 0:
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        if not hasattr(raw, "xbit_debug_set_gemv_variant"):
+            raise SystemExit("--variant needs a tuning build of the library (python -m xbitops_amd.build --tuning)")
+        raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
+        raw.xbit_debug_set_gemv_variant(args.variant)
 
-    nbytes = synth.algorithmic_bytes(K_IN, N_OUT, BITS, GROUP, BATCH)
-    copies = (COLD_BYTES + nbytes - 1) // nbytes + 1  # >= 512 MB of distinct weights
+    # ---- workload
+    if args.shape:
+        if world > 1:
+            raise SystemExit("--shape is a single-GPU workload")
+        k_in, n_full, bits, group, batch = (int(x) for x in args.shape.split(","))
+        scaling, workload = "weak", "A16W%d GEMV in=%d out=%d group=%d batch=%d (--shape)" % (bits, k_in, n_full, group, batch)
+        cfg_name = "shape"
+    else:
+        k_in, n_full, bits, group, batch, scaling, workload = CONFIGS[args.config]
+        cfg_name = args.config
     K, W = args.steps, args.warmup
 
     # ---- synthetic, seeded inputs resident in HBM before any timing
-    base = synth.make_problem(K_IN, N_OUT, BITS, GROUP, m=BATCH, seed=1000 + rank)
-    act = torch.from_numpy(base.act).to(dev)
+    if cfg_name == "cfg4":
+        # strong scaling: ONE 8192x28672 layer (same seed on every rank), this rank keeps its column shard
+        full = synth.make_problem(k_in, n_full, bits, group, m=batch, seed=4000)
+        qw_h, sc_h, qz_h = sharded.shard_columns(full.qweight, full.scales, full.qzeros, bits, world, rank)
+        act_h = full.act
+        del full
+    else:
+        # weak scaling: every rank owns one whole shard of a layer N times as wide (or the only one)
+        base = synth.make_problem(k_in, n_full, bits, group, m=batch, seed=1000 + rank)
+        qw_h, sc_h, qz_h, act_h = base.qweight, base.scales, base.qzeros, synth.make_problem(k_in, 2, bits, group, m=batch, seed=999).act
+        del base
+    n_local = qw_h.shape[1]
+    nbytes = synth.algorithmic_bytes(k_in, n_local, bits, group, batch)  # per rank and step
+    copies = (COLD_BYTES + nbytes - 1) // nbytes + 1  # >= 512 MB of distinct weights per GPU
+    act = torch.from_numpy(act_h).to(dev)
+    qw0, sc0, qz0 = torch.from_numpy(qw_h).to(dev), torch.from_numpy(sc_h).to(dev), torch.from_numpy(qz_h).to(dev)
     qws, scs, qzs = [], [], []
     for c in range(copies):
         # distinct contents per copy (xor with a per-copy word) so no two copies can be deduplicated
-        qw = torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))
-        qws.append(qw.contiguous())
-        scs.append(torch.from_numpy(base.scales).to(dev).clone())
-        qzs.append((torch.from_numpy(base.qzeros).to(dev) ^ (0x11111111 * (c % 13))).contiguous())
-    n_out_bufs = 2 * max(1, args.gather_bucket)
-    outs = torch.empty((n_out_bufs, BATCH, N_OUT), dtype=torch.float16, device=dev)
-    gathered = torch.empty((2, world, max(1, args.gather_bucket), BATCH, N_OUT), dtype=torch.float16, device=dev) if world > 1 else None
+        qws.append((qw0 ^ (0x01010101 * (c % 127))).contiguous())
+        scs.append(sc0.clone())
+        qzs.append((qz0 ^ (0x11111111 * (c % 13))).contiguous())
+    n_out_bufs = 4
+    outs = torch.empty((n_out_bufs, batch, n_local), dtype=torch.float16, device=dev)
+    gathered = torch.empty((n_out_bufs, world, batch, n_local), dtype=torch.float16, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
     a_ptr = act.data_ptr()
     ptrs = [(qws[c].data_ptr(), scs[c].data_ptr(), qzs[c].data_ptr()) for c in range(copies)]
     out_ptrs = [outs[i].data_ptr() for i in range(n_out_bufs)]
     gemv = lib.xbit_gemv_f16
+    stream = torch.cuda.current_stream(dev)
 
-    def step(i: int, stream_ptr: int) -> None:
+    def kernel_step(i: int, stream_ptr: int) -> None:
         qw, sc, qz = ptrs[i % copies]
-        st = gemv(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, BITS, GROUP, BATCH, K_IN, N_OUT, 1, stream_ptr)
+        st = gemv(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, bits, group, batch, k_in, n_local, 1, stream_ptr)
         if st != 0:
             _lib.check(st, "xbit_gemv_f16")
 
-    compute = torch.cuda.current_stream(dev)
-    comm = torch.cuda.Stream(dev) if world > 1 else None
-    bucket = max(1, args.gather_bucket)
-
-    gathered_ev = [None, None]  # per output half: the all-gather that last read it
-
-    def gather_bucket(b: int) -> None:
-        """all-gather the `bucket` outputs of bucket b on the side stream (after they are computed)."""
-        half = b % 2
-        src = outs[half * bucket:(half + 1) * bucket]
-        ev = torch.cuda.Event()
-        ev.record(compute)
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev)
-            dist.all_gather_into_tensor(gathered[half].view(-1), src.reshape(-1))
-            gathered_ev[half] = torch.cuda.Event()
-            gathered_ev[half].record(comm)
-
     def run_steps(first: int, count: int) -> None:
+        """The timed path: GEMV, then (sharded layer) the one all-gather of this step's output shards,
+        both ordered on the compute stream."""
         sp = torch.cuda.current_stream(dev).cuda_stream
         for i in range(first, first + count):
-            if world > 1 and i % bucket == 0 and gathered_ev[(i // bucket) % 2] is not None:
-                compute.wait_event(gathered_ev[(i // bucket) % 2])  # do not overwrite outputs still being gathered
-            step(i, sp)
-            if world > 1 and (i + 1) % bucket == 0:
-                gather_bucket(i // bucket)
+            kernel_step(i, sp)
+            if world > 1:
+                sharded.all_gather_output(gathered[i % n_out_bufs], outs[i % n_out_bufs])
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # ---- warm-up (untimed)
+    # ---- untimed: touch every weight copy once (a first touch pays GPU page-table walks: with W = 5 the
+    # timed steps would otherwise be the first to read most copies, +1.2 us per step), then W warm-up steps
+    sp0 = torch.cuda.current_stream(dev).cuda_stream
+    for c in range(copies):
+        kernel_step(c, sp0)
     run_steps(0, W)
-    if comm is not None:
-        compute.wait_stream(comm)
     torch.cuda.synchronize()
 
-    use_graph = (not args.no_graph) and world == 1
+    # ---- timed region: exactly K steps, HIP events on the compute stream, host clock beside them.
+    # One GPU: the K launches are queued behind a blocker kernel long enough to cover the host's
+    # enqueue time, so the event-to-event span holds device time only: K x (kernel + launch boundary).
+    # (A hipGraph replay measures the same per step — tools/bench_timing_probe.py — once its first,
+    # slower replay is out of the way; --graph times that instead.)
     graph = None
-    if use_graph:
+    if args.graph and world == 1:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             run_steps(W, K)
+        graph.replay()  # the first replay of a graph pays a one-off ~40 us on the device: untimed
         torch.cuda.synchronize()
-
-    # ---- timed region: exactly K steps
+    stream = torch.cuda.current_stream(dev)
+    blocker_cycles = 0
+    if world == 1:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        torch.cuda._sleep(1000000)
+        c1.record(stream)
+        torch.cuda.synchronize()
+        cycles_per_us = 1000000 / (c0.elapsed_time(c1) * 1e3)
+        blocker_cycles = int((100 + (0 if graph is not None else 12 * K)) * cycles_per_us)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if blocker_cycles:
+        torch.cuda._sleep(blocker_cycles)
+    ev0.record(stream)
     if graph is not None:
         graph.replay()
     else:
         run_steps(W, K)
-        if comm is not None:
-            # leftover partial bucket, then join the side stream
-            if (W + K) % bucket and world > 1:
-                gather_bucket((W + K) // bucket)
-            compute.wait_stream(comm)
+    ev1.record(stream)
+    t_queued = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_host = time.perf_counter() - t0
+    dt = ev0.elapsed_time(ev1) * 1e-3
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_host], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_host = float(t[0].item()), float(t[1].item())
 
-    # ---- kernel-only durations: HIP events bracketing each launch (cold rotation, then warm)
+    # ---- kernel-only durations: HIP events bracketing each launch, >= 200 cold launches whatever K is
     def profiled(n: int, rotate: bool):
         lib.xbit_profile_enable(1)
         ms = ctypes.c_float()
         vals = []
         sp = torch.cuda.current_stream(dev).cuda_stream
         for i in range(n):
-            step(W + K + i if rotate else 0, sp)
+            kernel_step(W + K + i if rotate else 0, sp)
             _lib.check(lib.xbit_profile_last_ms(ctypes.byref(ms)), "xbit_profile_last_ms")
             vals.append(ms.value)
         lib.xbit_profile_enable(0)
         return vals
 
     profiled(8, True)
-    cold = profiled(min(K, 400), True)
-    warm = profiled(min(K, 400), False)
+    cold = profiled(max(MIN_ROOFLINE_LAUNCHES, args.roofline_launches), True)
+    warm = profiled(200, False) if args.warm else None
     torch.cuda.synchronize()
     cold_avg = sum(cold) / len(cold)
-    warm_avg = sum(warm) / len(warm)
     cold_sorted = sorted(cold)
+    if world > 1:
+        t = torch.tensor([cold_avg], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest GPU's kernel
+        cold_avg = float(t.item())
 
     if rank == 0:
         achieved = nbytes / (cold_avg * 1e-3) / 1e9
         value = world * nbytes * K / dt / 1e9
-        traffic = pmc_traffic("A16W4 GEMV in=%d out=%d group=%d batch=%d" % (K_IN, N_OUT, GROUP, BATCH))
+        sha = lib_sha256(_lib.LIB_PATH)
+        off = offline_profile(workload if world == 1 else "", sha) if cfg_name != "shape" else None
+        traffic = off["traffic_bytes_per_launch"] if off and off.get("matches_this_build") else None
         rec = {
-            "metric": "A16W4 GEMV GB/s at 4096x11008 g128 batch=1 (algorithmic bytes / time; cold HBM)",
+            "metric": "A16W%d GEMV GB/s at %dx%d g%d batch=%d (algorithmic bytes / time; cold HBM)" % (bits, k_in, n_full, group, batch),
             "value": round(value, 2),
             "unit": "GB/s",
             "n_gpus": world,
@@ -281,36 +377,47 @@ def main():
             "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 6),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
             "config": {
-                "workload": "A16W4 GEMV in=4096 out=11008 group=128 batch=1 (Llama-7B FFN, BASELINE.json configs[1]) per GPU",
-                "bits": BITS, "groupsize": GROUP, "batch": BATCH, "algorithmic_bytes_per_step": nbytes,
-                "weight_copies_rotated": copies, "timed_region": "hipGraph replay of K launches" if graph is not None else "eager launches",
-                "parallelism": "column shards x%d + bucketed %s all-gather (bucket %d) on a side stream" % (
-                    world, "RCCL" if os.environ.get("XBIT_BENCH_BACKEND", "nccl") == "nccl" else os.environ["XBIT_BENCH_BACKEND"], bucket)
-                if world > 1 else "single GPU",
+                "workload": workload, "name": cfg_name,
+                "bits": bits, "groupsize": group, "batch": batch, "in_features": k_in, "out_features_per_gpu": n_local,
+                "algorithmic_bytes_per_step": nbytes, "weight_copies_rotated": copies,
+                "timed_region": ("hipGraph replay of K launches" if graph is not None else "K eager launches") + (
+                    " queued behind a blocker kernel" if world == 1 else " + K all-gathers") + ", HIP events on the compute stream",
+                "host_enqueue_us_per_step": round(1e6 * t_queued / K, 3),
+                "parallelism": ("column shards x%d (sharded.shard_columns) + one %s all_gather_into_tensor per step on the compute stream" % (
+                    world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
             },
+            "host_clock_ms_per_step": round(1e3 * dt_host / K, 6),
+            "end_to_end_us_per_step": round(1e6 * dt / K, 3),
+            "boundary_us_per_step": round(1e6 * dt / K - cold_avg * 1e3, 3),  # dependent-launch boundary (+ the all-gather on N > 1)
+            "kernel_gbps_per_gpu": round(achieved, 2),
+            "aggregate_kernel_gbps": round(world * achieved, 2),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic[1]["traffic_bytes_per_launch"] if traffic else None,
-                "rocprof_avg_kernel_us": (rocprof_kernel_avg_us() or (None, None))[1],
-                "rocprof_source": ((rocprof_kernel_avg_us() or (None, None))[0] or "") + ": rocprofv3 --kernel-trace --stats of this command; averages cold, graph and cache-warm launches and runs ~5-10 % slower under the profiler",
-                "traffic_source": (traffic[0] + ": rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, bytes per launch") if traffic else None,
+                "traffic": traffic,
                 "algorithmic_bytes": nbytes,
-                "kernel": "gemv_mfma_kernel<4,...>", "avg_kernel_us": round(cold_avg * 1e3, 3),
+                "kernel": "xbit_gemv_f16 dominant kernel (see profiles/ for its name)", "avg_kernel_us": round(cold_avg * 1e3, 3),
                 "median_kernel_us": round(cold_sorted[len(cold_sorted) // 2] * 1e3, 3), "min_kernel_us": round(cold_sorted[0] * 1e3, 3),
-                "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch",
-                "warm_cache_avg_kernel_us": round(warm_avg * 1e3, 3), "warm_cache_gbps": round(nbytes / (warm_avg * 1e-3) / 1e9, 2),
+                "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch, cold weights" + (", max over GPUs" if world > 1 else ""),
             },
-            "tok_per_s_proxy": round(achieved * 1e9 / 3.37e9, 1),
+            "offline_profile": off,
+            "tok_per_s_proxy": round(achieved * 1e9 / 3.37e9, 1) if cfg_name == "cfg2" else None,
             "tok_per_s_formula": "roofline.achieved GB/s / 3.37 GB of w4g128 linear weights per token of a 7B model",
+            "lib_sha256": sha,
         }
+        if warm is not None:
+            warm_avg = sum(warm) / len(warm)
+            rec["roofline"]["warm_cache_avg_kernel_us"] = round(warm_avg * 1e3, 3)
+            rec["roofline"]["warm_cache_gbps"] = round(nbytes / (warm_avg * 1e-3) / 1e9, 2)
         if world == 1 and not args.no_cpu:
-            rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, nbytes)
+            port, prob, y_port = cpu_baseline_port(args.cpu_seconds, k_in, n_local, bits, group, batch, nbytes)
+            port["torch_cpu"] = cpu_baseline_torch(prob, y_port, bits, group, k_in, nbytes, args.cpu_seconds)
+            rec["cpu_baseline"] = port
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

@@ -28,7 +28,7 @@ def _free_port():
 
 def _oracle_gemv(a, qweight, scales, qzeros, groupsize, bits, in_features, add_zero_bias):
     y = oracle.gemv(a.numpy(), qweight.numpy(), scales.numpy(), qzeros.numpy(), groupsize, bits, in_features, add_zero_bias)
-    return torch.from_numpy(y)
+    return torch.from_numpy(y).reshape(*a.shape[:-1], qweight.shape[1])  # leading dimensions as the operator returns them
 
 
 def _worker(rank, world, port, bits, k, n, g, m, bias, ret):
@@ -49,6 +49,16 @@ def _worker(rank, world, port, bits, k, n, g, m, bias, ret):
         w_full = oracle.dequant(p.qweight, p.scales, p.qzeros, g, bits, k, bias)
         n0, n1 = sharded.shard_bounds(n, bits, world, rank)
         ok = ok and np.array_equal(w_shard.view(np.uint16), w_full[:, n0:n1].view(np.uint16))
+        # [B, S, K] activations: leading dimensions survive the gather (the operator accepts them, dq_torch_ops.cc:59-63)
+        if m % 2 == 0:
+            y3 = op(t(p.act).reshape(2, m // 2, k))
+            ok = ok and y3.shape == (2, m // 2, n) and np.array_equal(y3.reshape(m, n).numpy().view(np.uint16), y_full.view(np.uint16))
+        # bench.py's per-step sequence (--config cfg4): local GEMV into a preallocated shard, then the ONE
+        # all-gather into a preallocated [P, M, N/P] buffer on the same stream
+        out_local = op.local(t(p.act)).contiguous()
+        gathered = torch.empty((world, m, op.n_local), dtype=out_local.dtype)
+        sharded.all_gather_output(gathered, out_local)
+        ok = ok and np.array_equal(sharded.full_from_gathered(gathered).numpy().view(np.uint16), y_full.view(np.uint16))
         ret[rank] = bool(ok)
         dist.barrier()
     finally:
@@ -60,6 +70,7 @@ def _worker(rank, world, port, bits, k, n, g, m, bias, ret):
     (2, 3, 256, 128, 64, 3, 0),
     (4, 5, 256, 512, 128, 1, 1),
     (2, 8, 128, 64, 32, 2, 0),
+    (2, 4, 256, 7168 // 4, 128, 4, 1),  # the cfg4 split pattern (N/P on a qzeros word boundary), batch 4 as [2, 2, K]
 ])
 def test_column_sharded_gemv_over_gloo(world, bits, k, n, g, m, bias):
     ctx = mp.get_context("spawn")

@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 from .packing import packed_rows
 
-__all__ = ["shard_bounds", "shard_columns", "ShardedGemv"]
+__all__ = ["shard_bounds", "shard_columns", "all_gather_output", "full_from_gathered", "ShardedGemv"]
 
 
 def shard_bounds(n: int, bits: int, world: int, rank: int):
@@ -47,6 +47,20 @@ def shard_columns(qweight, scales, qzeros, bits: int, world: int, rank: int):
     if isinstance(qweight, torch.Tensor):
         return qw.contiguous(), sc.contiguous(), qz.contiguous()
     return np.ascontiguousarray(qw), np.ascontiguousarray(sc), np.ascontiguousarray(qz)
+
+
+def all_gather_output(gathered: torch.Tensor, y_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
+    """The ONE collective of a column-sharded layer: ``gathered[r] = rank r's [M, N/P] output shard``.
+    Issued on the current stream right behind the kernel (``bench.py`` times exactly this per step)."""
+    dist.all_gather_into_tensor(gathered.view(-1), y_local.view(-1), group=group)
+
+
+def full_from_gathered(gathered: torch.Tensor) -> torch.Tensor:
+    """``[P, M, N/P]`` rank-major shards -> ``[M, N]``.  One row: rank-major IS column-major, no copy."""
+    world, m, n_local = gathered.shape
+    if m == 1:
+        return gathered.view(1, world * n_local)
+    return gathered.permute(1, 0, 2).reshape(m, world * n_local)
 
 
 class ShardedGemv:
@@ -77,13 +91,13 @@ class ShardedGemv:
         return self._gemv(a, self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
 
     def __call__(self, a: torch.Tensor) -> torch.Tensor:
-        """Full ``[M, N]`` output on every rank: local GEMV + one all-gather of the output shards."""
+        """Full ``[..., N]`` output on every rank: local GEMV + one all-gather of the output shards.
+        ``a`` is ``[M, K]`` or ``[B, S, K]`` as for the operator (dq_torch_ops.cc:59-63)."""
         y_local = self.local(a)
         if self.world == 1:
             return y_local
-        m = y_local.shape[0]
-        gathered = torch.empty((self.world, m, self.n_local), dtype=y_local.dtype, device=y_local.device)
-        dist.all_gather_into_tensor(gathered.view(-1), y_local.contiguous().view(-1), group=self.group)
-        if m == 1:
-            return gathered.view(1, self.world * self.n_local)  # rank-major == column-major for one row: no copy
-        return gathered.permute(1, 0, 2).reshape(m, self.world * self.n_local)
+        lead = y_local.shape[:-1]
+        y2 = y_local.reshape(-1, self.n_local)  # leading dimensions flattened: the gather works on [M, N/P]
+        gathered = torch.empty((self.world, y2.shape[0], self.n_local), dtype=y2.dtype, device=y2.device)
+        all_gather_output(gathered, y2.contiguous(), self.group)
+        return full_from_gathered(gathered).reshape(*lead, self.world * self.n_local)
