@@ -214,12 +214,10 @@ def main(argv=None):
             dist.init_process_group(backend)
 
     lib = _lib.load()  # raises if the HIP library is missing
-    if args.variant >= 0:
-        raw = ctypes.CDLL(_lib.LIB_PATH)
-        if not hasattr(raw, "xbit_debug_set_gemv_variant"):
-            raise SystemExit("--variant needs a tuning build of the library (python -m xbitops_amd.build --tuning)")
-        raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
-        raw.xbit_debug_set_gemv_variant(args.variant)
+    gemv_opts = None
+    if args.variant > 0:
+        lib = _lib.load_tuning()  # measurement variants live in the tuning build (python -m xbitops_amd.build --tuning)
+        gemv_opts = _lib.GemvOptions(variant=args.variant)
 
     # ---- workload
     if args.shape:
@@ -269,7 +267,10 @@ def main(argv=None):
 
     def kernel_step(i: int, stream_ptr: int) -> None:
         qw, sc, qz = ptrs[i % copies]
-        st = gemv(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, bits, group, batch, k_in, n_local, 1, stream_ptr)
+        if gemv_opts is None:
+            st = gemv(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, bits, group, batch, k_in, n_local, 1, stream_ptr)
+        else:
+            st = lib.xbit_gemv_f16_ex(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, bits, group, batch, k_in, n_local, 1, stream_ptr, gemv_opts)
         if st != 0:
             _lib.check(st, "xbit_gemv_f16")
 
@@ -365,7 +366,7 @@ def main(argv=None):
     if rank == 0:
         achieved = nbytes / (cold_avg * 1e-3) / 1e9
         value = world * nbytes * K / dt / 1e9
-        sha = lib_sha256(_lib.LIB_PATH)
+        sha = lib_sha256(_lib.TUNING_LIB_PATH if gemv_opts is not None else _lib.LIB_PATH)
         off = offline_profile(workload if world == 1 else "", sha) if cfg_name != "shape" else None
         traffic = off["traffic_bytes_per_launch"] if off and off.get("matches_this_build") else None
         rec = {

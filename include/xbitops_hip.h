@@ -36,15 +36,32 @@
  * (gemv_w4a16_pt.cu:152-155,168-172; unpack_weight_2_to_7.cu:436-440).  These functions never
  * abort: they return 0 on success, a negative XBIT_ERR_* for a rejected argument, or a positive
  * hipError_t if the HIP runtime refused the launch.  Launches are asynchronous on `hip_stream`.
- * The library is safe to call from several host threads.  Its only state is a 2 MiB scratch buffer
- * per (device, stream), allocated the first time a GEMV with few output columns (N <= 4608) and
- * K >= 8192 is split over K on that stream (never inside a stream capture).
+ * The library is safe to call from several host threads.
+ *
+ * State.  A GEMV with few output columns and a long K is split over K (several workgroups per
+ * column tile); the partial sums meet in 64-bit accumulators that must be zero when the launch
+ * starts and are zero again when it ends.  That scratch is either
+ *   - the caller's: xbit_gemv_f16_ex(..., &options) with options.workspace set (one launch at a time
+ *     per buffer; xbit_gemv_workspace_bytes says how much), or
+ *   - the library's: one 2 MiB buffer per (device, stream) for eager launches (launches on a stream
+ *     run in order, so they can share it) and, for a launch recorded by a stream capture, a private
+ *     range of a per-device pool that is never handed out again - a captured graph may replay on any
+ *     stream, concurrently with anything, so it cannot share.  Nothing is allocated inside a capture:
+ *     the pool is created by the first eager split-K launch on the device or by xbit_workspace_reset().
+ *     If no scratch can be had (no pool yet, allocation failure, pool exhausted) the launch simply
+ *     is not split; the result differs from the split one only in the fp32 summation order.
+ * xbit_workspace_reset() creates the pool if needed and re-zeroes the library's buffers; the library
+ * re-zeroes by itself after a launch error, a host that killed work on the device by other means
+ * calls it.
  */
 #ifndef XBITOPS_HIP_H_
 #define XBITOPS_HIP_H_
 
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header's functions are exported */
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -57,9 +74,11 @@ extern "C" {
 #define XBIT_ERR_SHAPE (-4)        /* m, k or n is 0, n is odd (the reference stores column pairs,
                                       unpack_weight_2_to_7.cu:48,62), or a size overflows 32 bits */
 #define XBIT_ERR_ALIGNMENT (-5)    /* a pointer is not aligned to its element size */
+#define XBIT_ERR_UNSUPPORTED (-6)  /* an option this build of the library does not implement (measurement
+                                      variants exist only in libxbitops_hip_tuning.so) */
 
 /* ABI version of this header; bumped on any signature change. */
-#define XBIT_ABI_VERSION 1
+#define XBIT_ABI_VERSION 2
 int xbit_abi_version(void);
 
 /* Human-readable text for a status returned by this library (negative XBIT_ERR_*, 0, or a
@@ -83,6 +102,35 @@ int xbit_dequant_f16(void* out, const void* qweight, const void* scales, const v
 int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
                   int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream);
 
+/* Per-call options of xbit_gemv_f16_ex.  Zero-initialise, set struct_bytes = sizeof(xbit_gemv_options),
+ * then the fields you need; fields beyond struct_bytes take their defaults (the struct may grow). */
+typedef struct xbit_gemv_options {
+  uint32_t struct_bytes;
+  int32_t split_k;          /* 0 = choose (default); 1 = never split K; 2..15 = split K that many ways when the
+                               shape has a fast path (otherwise ignored).  Results differ only in summation order. */
+  void* workspace;          /* caller-owned split-K scratch: device memory, zero-filled, >= xbit_gemv_workspace_bytes(m, n),
+                               used by ONE launch at a time (it is zero again when that launch has finished).  NULL
+                               (default) = library-managed, see "State" above. */
+  uint64_t workspace_bytes; /* size of `workspace` */
+  int32_t variant;          /* -1 or 0 = production launch (default).  > 0: measurement variant, tuning build only */
+  int32_t reserved;
+  void* trace;              /* tuning build only: device buffer for the stamped measurement kernel */
+} xbit_gemv_options;
+
+/* xbit_gemv_f16 with options (NULL options = xbit_gemv_f16). */
+int xbit_gemv_f16_ex(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
+                     int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream,
+                     const xbit_gemv_options* options);
+
+/* Bytes of zero-filled scratch that a split-K launch of an [m, k] x [k, n] GEMV may need at most
+ * (8 bytes per output element, rounded up to whole column tiles and row passes). */
+uint64_t xbit_gemv_workspace_bytes(uint32_t m, uint32_t n);
+
+/* Create the capture pool if it does not exist yet and re-zero every library-managed scratch buffer of
+ * the current device (synchronises the device; not to be called while a stream is being captured).
+ * Returns 0 or a positive hipError_t. */
+int xbit_workspace_reset(void);
+
 /* Extension (not in the reference): one activation against `count` (1..4) weight sets that share k,
  * bits and groupsize - q/k/v or gate/up of a decoder layer - in ONE launch when the shape allows
  * (m <= 4 and the fast path's alignment rules), otherwise as `count` xbit_gemv_f16 launches; results
@@ -104,6 +152,9 @@ int xbit_profile_last_ms(float* ms);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 
 #endif /* XBITOPS_HIP_H_ */

@@ -29,7 +29,13 @@ def test_library_exports_every_declared_symbol(native_lib):
     for name in declared_symbols():
         assert hasattr(raw, name), name
     assert sorted(_lib.EXPORTS) == declared_symbols()
-    assert native_lib.xbit_abi_version() == 1
+    assert native_lib.xbit_abi_version() == 2
+    # only the declared C ABI is visible: no C++ internals, no process-global tuning setters
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+    assert exported == declared_symbols(), exported
 
 
 def test_library_has_no_torch_dependency(native_lib):
@@ -46,7 +52,7 @@ def test_status_strings(native_lib):
     from xbitops_amd import _lib
 
     assert _lib.status_string(0) == "success"
-    for code in (-1, -2, -3, -4, -5):
+    for code in (-1, -2, -3, -4, -5, -6):
         assert _lib.status_string(code).startswith("xbitops:")
     with pytest.raises(RuntimeError, match="bits must be in 2..8"):
         _lib.check(-2, "x")
@@ -66,6 +72,13 @@ def test_capi_rejects_bad_arguments_before_touching_the_gpu(native_lib):
     assert lib.xbit_dequant_f16(p, p, p, p, 0, 128, 128, 64, 0, None) == -2
     assert lib.xbit_dequant_f16(p, p, p, p, 4, 128, 0, 64, 0, None) == -4
     assert lib.xbit_profile_last_ms(None) == -1
+    from xbitops_amd._lib import GemvOptions
+
+    assert lib.xbit_gemv_f16_ex(p, p, p, p, p, 4, 128, 1, 128, 64, 0, None, GemvOptions(split_k=16)) == -4   # split factor out of range
+    assert lib.xbit_gemv_f16_ex(p, p, p, p, p, 4, 128, 1, 128, 64, 0, None, GemvOptions(variant=64)) == -6   # production build: no variants
+    assert lib.xbit_gemv_f16_ex(p, p, p, p, p, 4, 128, 1, 128, 64, 0, None, GemvOptions(workspace=p + 4, workspace_bytes=64)) == -5
+    assert lib.xbit_gemv_f16_ex(None, p, p, p, p, 4, 128, 1, 128, 64, 0, None, None) == -1
+    assert lib.xbit_gemv_workspace_bytes(1, 3584) == 8 * 3584 and lib.xbit_gemv_workspace_bytes(3, 130) == 8 * 4 * 192
 
 
 def _cpu_args(k=128, n=64, bits=4, g=128):

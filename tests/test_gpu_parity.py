@@ -242,34 +242,28 @@ def test_dequant_full_size_digest_shapes(name, cuda_device):
 
 def test_mfma_and_valu_accumulate_builds_agree(cuda_device):
     """DESIGN.md's A/B of the north star's "no MFMA" design: the measurement build that accumulates
-    on the VALU (v_dot2_f32_f16 + shuffles, variant 64) must give the production (MFMA) kernel's
-    result up to the fp32 summation order, and both must meet the oracle."""
-    import ctypes
+    on the VALU (v_dot2_f32_f16 + shuffles, variant 64 of the tuning library) must give the production
+    (MFMA) kernel's result up to the fp32 summation order, and both must meet the oracle."""
+    from xbitops_amd import _lib, ops
 
-    import XbitOps
-    from xbitops_amd import _lib
-
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    if not hasattr(raw, "xbit_debug_set_gemv_variant"):
-        pytest.skip("library built without the measurement variants (XBIT_TUNING=0)")
-    raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
-    try:
-        for k, n in ((4096, 11008), (4096, 1008), (2048, 512)):
-            p = synth.make_problem(k, n, 4, 128, m=1, seed=64 + n)
-            a, qw, sc, qz = to_dev(p, cuda_device)
-            y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
-            raw.xbit_debug_set_gemv_variant(-1)
-            y_mfma = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
-            raw.xbit_debug_set_gemv_variant(64)
-            y_valu = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
-            torch.cuda.synchronize()
-            assert_gemv_close(y_mfma.cpu().numpy(), y_ref, "mfma k=%d n=%d" % (k, n))
-            assert_gemv_close(y_valu.cpu().numpy(), y_ref, "valu k=%d n=%d" % (k, n))
-            d = (y_mfma.view(torch.int16).int() - y_valu.view(torch.int16).int()).abs()
-            close = (d <= 1) | ((y_mfma.float() - y_valu.float()).abs() <= 4e-6)  # last fp16 bit, or fp32 noise where the sum cancels
-            assert bool(close.all()) and float((d == 0).float().mean()) > 0.98
-    finally:
-        raw.xbit_debug_set_gemv_variant(-1)
+    if not os.path.exists(_lib.TUNING_LIB_PATH):
+        pytest.skip("tuning library not built (python -m xbitops_amd.build --tuning)")
+    for k, n in ((4096, 11008), (4096, 1008), (2048, 512)):
+        p = synth.make_problem(k, n, 4, 128, m=1, seed=64 + n)
+        a, qw, sc, qz = to_dev(p, cuda_device)
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+        y_mfma = ops.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        y_valu = ops.gemv_ex(a, qw, sc, qz, 128, 4, k, 1, variant=64)
+        torch.cuda.synchronize()
+        assert_gemv_close(y_mfma.cpu().numpy(), y_ref, "mfma k=%d n=%d" % (k, n))
+        assert_gemv_close(y_valu.cpu().numpy(), y_ref, "valu k=%d n=%d" % (k, n))
+        d = (y_mfma.view(torch.int16).int() - y_valu.view(torch.int16).int()).abs()
+        close = (d <= 1) | ((y_mfma.float() - y_valu.float()).abs() <= 4e-6)  # last fp16 bit, or fp32 noise where the sum cancels
+        assert bool(close.all()) and float((d == 0).float().mean()) > 0.98
+    with pytest.raises(RuntimeError, match="not supported by this build"):  # the production library has no variants
+        st = _lib.load().xbit_gemv_f16_ex(y_mfma.data_ptr(), a.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), 4, 128, 1, k, n, 1,
+                                          torch.cuda.current_stream().cuda_stream, _lib.GemvOptions(variant=64))
+        _lib.check(st, "xbit_gemv_f16_ex")
 
 
 def test_gemv_linearity_full_size(cuda_device):
@@ -428,71 +422,123 @@ def test_gemv_rebuilds_w_bit_exact_one_hot(bits, cuda_device):
 
 @pytest.mark.parametrize("bits", [3, 4, 8])
 def test_gemv_split_k_shapes(bits, cuda_device):
-    """Small N and long K: the launcher splits K over workgroups (partial sums in the per-stream
-    workspace, the last arriver adds them in split order).  Repeated launches reuse the tickets; a
-    second stream gets its own workspace; ragged K / N and M = 3, 4 go through the same path.  The
-    last case forces a split factor on a shape the heuristic would not split."""
-    import ctypes
-
+    """Small N and long K: the launcher splits K over workgroups (fixed-point partial sums in scratch,
+    the last arriver converts).  Repeated launches reuse the scratch; a second stream gets its own;
+    ragged K / N and M = 3, 4 go through the same path.  The last cases force a split factor
+    (options.split_k) on shapes the heuristic would not split."""
     import XbitOps
-    from xbitops_amd import _lib
+    from xbitops_amd import ops
 
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
-    try:
-        for k, n, m, forced in ((16384, 256, 1, 0), (14336 + 512, 130, 3, 0), (14336, 512, 4, 0), (4096 + 512, 130, 3, 3), (8192, 1024, 1, 5)):
-            raw.xbit_debug_set_gemv_split(forced)
-            p = synth.make_problem(k, n, bits, 128, m=m, seed=bits * 41 + n + m)
-            y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, k, 1, oracle.RNE)
-            a, qw, sc, qz = to_dev(p, cuda_device)
-            ys = [XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1) for _ in range(3)]
-            side = torch.cuda.Stream(device=cuda_device)
-            side.wait_stream(torch.cuda.current_stream(cuda_device))
-            with torch.cuda.stream(side):
-                ys.append(XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1))
-            torch.cuda.synchronize()
-            for y in ys:
-                assert_gemv_close(y.cpu().numpy(), y_ref, "bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
-                assert torch.equal(y, ys[0])  # fixed summation order: launches agree bit for bit
-            raw.xbit_debug_set_gemv_split(1)  # never split: same result up to the summation order
-            y1 = XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1)
-            assert_gemv_close(y1.cpu().numpy(), y_ref, "unsplit bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
-    finally:
-        raw.xbit_debug_set_gemv_split(0)
+    for k, n, m, forced in ((16384, 256, 1, 0), (14336 + 512, 130, 3, 0), (14336, 512, 4, 0), (4096 + 512, 130, 3, 3), (8192, 1024, 1, 5)):
+        p = synth.make_problem(k, n, bits, 128, m=m, seed=bits * 41 + n + m)
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, k, 1, oracle.RNE)
+        a, qw, sc, qz = to_dev(p, cuda_device)
+        ys = [ops.gemv_ex(a, qw, sc, qz, 128, bits, k, 1, split_k=forced) for _ in range(3)]
+        side = torch.cuda.Stream(device=cuda_device)
+        side.wait_stream(torch.cuda.current_stream(cuda_device))
+        with torch.cuda.stream(side):
+            ys.append(ops.gemv_ex(a, qw, sc, qz, 128, bits, k, 1, split_k=forced))
+        torch.cuda.synchronize()
+        for y in ys:
+            assert_gemv_close(y.cpu().numpy(), y_ref, "bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
+            assert torch.equal(y, ys[0])  # fixed-point accumulation: launches agree bit for bit
+        y1 = ops.gemv_ex(a, qw, sc, qz, 128, bits, k, 1, split_k=1)  # never split: same result up to the summation order
+        assert_gemv_close(y1.cpu().numpy(), y_ref, "unsplit bits=%d k=%d n=%d m=%d" % (bits, k, n, m))
+        if forced == 0:
+            assert torch.equal(XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1), ys[0])  # the plain operator takes the same path
+
+
+def test_split_k_with_caller_workspace(cuda_device):
+    """options.workspace: the caller's zero-filled scratch is used (and left zero); one that is too
+    small is never used (the launch runs unsplit instead of touching it)."""
+    from xbitops_amd import _lib, ops
+
+    k, n = 16384, 512
+    p = synth.make_problem(k, n, 4, 128, m=1, seed=77)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+    a, qw, sc, qz = to_dev(p, cuda_device)
+    need = int(_lib.load().xbit_gemv_workspace_bytes(1, n))
+    assert need == 8 * 512
+    ws = torch.zeros(need // 8, dtype=torch.int64, device=cuda_device)
+    y = ops.gemv_ex(a, qw, sc, qz, 128, 4, k, 1, workspace=ws)
+    y2 = ops.gemv_ex(a, qw, sc, qz, 128, 4, k, 1, workspace=ws)  # reusable at once: the kernel left it zero
+    torch.cuda.synchronize()
+    assert_gemv_close(y.cpu().numpy(), y_ref, "caller workspace")
+    assert torch.equal(y, y2) and int(ws.abs().sum()) == 0
+    assert torch.equal(y, ops.gemv(a, qw, sc, qz, 128, 4, k, 1))  # library-managed scratch: same split, same bits
+    poisoned = torch.full((16,), -1, dtype=torch.int64, device=cuda_device)  # too small: must not be touched
+    y3 = ops.gemv_ex(a, qw, sc, qz, 128, 4, k, 1, workspace=poisoned)
+    torch.cuda.synchronize()
+    assert_gemv_close(y3.cpu().numpy(), y_ref, "workspace too small -> unsplit")
+    assert bool((poisoned == -1).all())
+    assert _lib.load().xbit_workspace_reset() == 0
+    assert torch.equal(ops.gemv(a, qw, sc, qz, 128, 4, k, 1), y)
+
+
+def test_two_captured_split_k_graphs_replay_concurrently(cuda_device):
+    """two split-K launches captured into two hipGraphs (torch captures both on one stream)
+    and replayed AT THE SAME TIME on two streams, beside eager split-K launches on a third: each captured
+    launch owns a private scratch range, so every replay gives the eager result bit for bit."""
+    from xbitops_amd import ops
+
+    cases = []
+    for k, n, seed in ((16384, 512, 5), (28672, 256, 6)):
+        p = synth.make_problem(k, n, 4, 128, m=1, seed=seed)
+        a, qw, sc, qz = to_dev(p, cuda_device)
+        want = ops.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+        assert_gemv_close(want.cpu().numpy(), y_ref, "eager k=%d" % k)
+        cases.append((k, a, qw, sc, qz, want))
+    torch.cuda.synchronize()
+    graphs = []
+    for k, a, qw, sc, qz, want in cases:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = ops.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        graphs.append((g, y, want))
+    streams = [torch.cuda.Stream(device=cuda_device) for _ in range(3)]
+    bad = []
+    for rep in range(30):
+        for (g, y, _want), st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                y.zero_()
+                g.replay()
+        with torch.cuda.stream(streams[2]):
+            k, a, qw, sc, qz, want_eager = cases[rep % 2]
+            y_eager = ops.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        torch.cuda.synchronize()
+        for i, (g, y, want) in enumerate(graphs):
+            if not torch.equal(y, want):
+                bad.append((rep, i))
+        if not torch.equal(y_eager, want_eager):
+            bad.append((rep, "eager"))
+    assert not bad, bad
 
 
 def test_gemv_random_shapes(cuda_device):
     """Seeded random shapes through every launch path the heuristics can take (whole-K tiles of
     16/32/48/64/128 columns, 1/4/8/16 rows per pass, forced and automatic split-K, the generic
     kernel for K % 8 != 0 or groups that are not a multiple of 32), ragged K and N included."""
-    import ctypes
+    from xbitops_amd import ops
 
-    import XbitOps
-    from xbitops_amd import _lib
-
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
     rng = np.random.default_rng(2024)
-    try:
-        for case in range(48):
-            bits = int(rng.integers(2, 9))
-            g = int(rng.choice([16, 32, 64, 96, 128, 256]))
-            k = int(rng.integers(1, 40)) * g + int(rng.choice([0, 0, 8, 24, g // 2]))
-            if rng.random() < 0.15:
-                k += 4  # K % 8 != 0: generic kernel
-            n = int(rng.choice([2, 34, 96, 130, 256, 1000, 4096 + 6, 11008, 25600 + 62]))
-            m = int(rng.choice([1, 1, 1, 2, 4, 5, 8, 13, 16, 21]))
-            if k * n > 3e7:
-                k = max(g, (int(3e7 // n) // g) * g)
-            forced = int(rng.choice([0, 0, 0, 2, 3, 5]))
-            raw.xbit_debug_set_gemv_split(forced)
-            bias = int(rng.integers(0, 2))
-            p = synth.make_problem(k, n, bits, g, m=m, seed=7000 + case)
-            y = run_gemv(p, bias, cuda_device)
-            y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, bias, oracle.RNE)
-            assert_gemv_close(y, y_ref, "case %d bits=%d k=%d n=%d g=%d m=%d bias=%d split=%d" % (case, bits, k, n, g, m, bias, forced))
-    finally:
-        raw.xbit_debug_set_gemv_split(0)
+    for case in range(48):
+        bits = int(rng.integers(2, 9))
+        g = int(rng.choice([16, 32, 64, 96, 128, 256]))
+        k = int(rng.integers(1, 40)) * g + int(rng.choice([0, 0, 8, 24, g // 2]))
+        if rng.random() < 0.15:
+            k += 4  # K % 8 != 0: generic kernel
+        n = int(rng.choice([2, 34, 96, 130, 256, 1000, 4096 + 6, 11008, 25600 + 62]))
+        m = int(rng.choice([1, 1, 1, 2, 4, 5, 8, 13, 16, 21]))
+        if k * n > 3e7:
+            k = max(g, (int(3e7 // n) // g) * g)
+        forced = int(rng.choice([0, 0, 0, 2, 3, 5]))
+        bias = int(rng.integers(0, 2))
+        p = synth.make_problem(k, n, bits, g, m=m, seed=7000 + case)
+        a, qw, sc, qz = to_dev(p, cuda_device)
+        y = ops.gemv_ex(a, qw, sc, qz, g, bits, k, bias, split_k=forced).cpu().numpy()
+        y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, bias, oracle.RNE)
+        assert_gemv_close(y, y_ref, "case %d bits=%d k=%d n=%d g=%d m=%d bias=%d split=%d" % (case, bits, k, n, g, m, bias, forced))
 
 
 def test_dequant_random_shapes_bit_exact(cuda_device):
@@ -612,13 +658,8 @@ def test_gemv_multi_fused_launch(bits, cuda_device):
 def test_split_k_overflow_and_nan_follow_the_unsplit_result(cuda_device):
     """Split-K accumulates in fixed point; partial sums outside its range, Inf and NaN must still give
     what the unsplit kernel stores: +Inf / -Inf on overflow, NaN for NaN (or Inf - Inf)."""
-    import ctypes
+    from xbitops_amd import ops
 
-    import XbitOps
-    from xbitops_amd import _lib
-
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
     k, n = 16384, 256
     p = synth.make_problem(k, n, 4, 128, m=1, seed=321)
     act = p.act.copy()
@@ -626,19 +667,14 @@ def test_split_k_overflow_and_nan_follow_the_unsplit_result(cuda_device):
     sc[:, 0:64] = 200.0     # columns 0-63: huge positive/negative sums -> +-Inf in fp16
     p.scales = sc.astype(np.float16)
     a, qw, scd, qz = (torch.from_numpy(x).to(cuda_device) for x in (act, p.qweight, p.scales, p.qzeros))
-    try:
-        raw.xbit_debug_set_gemv_split(1)
-        want = XbitOps.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
-        raw.xbit_debug_set_gemv_split(0)
-        got = XbitOps.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
-        big = ~np.isfinite(want)
-        assert big[:, :64].any()                       # the test does overflow
-        assert np.array_equal(np.isnan(got), np.isnan(want))
-        assert np.array_equal(got[big & ~np.isnan(want)], want[big & ~np.isnan(want)])   # same signed infinities
-        assert_gemv_close(got[~big], want[~big], "finite columns")
-        act[0, 7] = np.float16(np.nan)                 # a NaN activation poisons every output
-        a = torch.from_numpy(act).to(cuda_device)
-        got = XbitOps.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
-        assert np.isnan(got).all()
-    finally:
-        raw.xbit_debug_set_gemv_split(0)
+    want = ops.gemv_ex(a, qw, scd, qz, 128, 4, k, 1, split_k=1).cpu().numpy()
+    got = ops.gemv_ex(a, qw, scd, qz, 128, 4, k, 1, split_k=0).cpu().numpy()
+    big = ~np.isfinite(want)
+    assert big[:, :64].any()                       # the test does overflow
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[big & ~np.isnan(want)], want[big & ~np.isnan(want)])   # same signed infinities
+    assert_gemv_close(got[~big], want[~big], "finite columns")
+    act[0, 7] = np.float16(np.nan)                 # a NaN activation poisons every output
+    a = torch.from_numpy(act).to(cuda_device)
+    got = ops.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
+    assert np.isnan(got).all()

@@ -35,7 +35,7 @@ def measure(lib, fn, n=200, warm=10):
     return sum(vals) / len(vals), vals[len(vals) // 2], vals[0]
 
 
-def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200):
+def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, split=0):
     nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
     copies = (COLD_BYTES + nbytes - 1) // nbytes + 1 if cold else 1
     base = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
@@ -46,9 +46,11 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200):
     out = torch.empty((m, n), dtype=torch.float16, device=dev)
     sp = torch.cuda.current_stream(dev).cuda_stream
 
+    opts = _lib.GemvOptions(split_k=split, variant=variant)
+
     def fn(i):
         c = i % copies
-        st = lib.xbit_gemv_f16(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp)
+        st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, opts)
         assert st == 0, st
 
     avg, med, mn = measure(lib, fn, iters)
@@ -82,27 +84,21 @@ def show(name, nbytes, avg, med, mn):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--variants", default="-1", help="-1 = production launch (production library); > 0 = measurement variants (tuning library)")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--shape", default="4096,11008,4,128,1", help="K,N,bits,group,M for the variant loop")
     ap.add_argument("--splits", default="0", help="split-K factors to try per variant (0 = automatic, 1 = never split)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load()
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
     print("device:", torch.cuda.get_device_name(0), flush=True)
     sk, sn, sb, sg, sm = (int(x) for x in args.shape.split(","))
-    raw.xbit_debug_set_gemv_split.argtypes = [ctypes.c_int]
     for v in [int(x) for x in args.variants.split(",") if x != ""]:
+        vlib = _lib.load_tuning() if v > 0 else lib  # measurement variants live in the tuning build only
         for sp in [int(x) for x in args.splits.split(",")]:
-            raw.xbit_debug_set_gemv_variant(v)
-            raw.xbit_debug_set_gemv_split(sp)
             tag = "variant %d" % v + (" split %d" % sp if sp else "")
-            show("gemv w%d %dx%d m%d %s cold" % (sb, sk, sn, sm, tag), *gemv_case(lib, dev, sk, sn, sb, sg, sm, True, 100 if sk * sn > 1e8 else 200))
-            show("gemv w%d %dx%d m%d %s warm" % (sb, sk, sn, sm, tag), *gemv_case(lib, dev, sk, sn, sb, sg, sm, False, 100 if sk * sn > 1e8 else 200))
-    raw.xbit_debug_set_gemv_variant(-1)
-    raw.xbit_debug_set_gemv_split(0)
+            show("gemv w%d %dx%d m%d %s cold" % (sb, sk, sn, sm, tag), *gemv_case(vlib, dev, sk, sn, sb, sg, sm, True, 100 if sk * sn > 1e8 else 200, v, sp))
+            show("gemv w%d %dx%d m%d %s warm" % (sb, sk, sn, sm, tag), *gemv_case(vlib, dev, sk, sn, sb, sg, sm, False, 100 if sk * sn > 1e8 else 200, v, sp))
     if args.quick:
         return
     show("gemv w4 8192x28672 m1 cold (cfg4, 1 GPU)", *gemv_case(lib, dev, 8192, 28672, 4, 128, 1, True, 60))

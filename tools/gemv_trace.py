@@ -26,10 +26,7 @@ def main():
     ap.add_argument("--shape", default="4096,11008", help="K,N")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    lib = _lib.load()
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    raw.xbit_debug_set_gemv_variant.argtypes = [ctypes.c_int]
-    raw.xbit_debug_set_gemv_trace.argtypes = [ctypes.c_void_p]
+    lib = _lib.load_tuning()  # the stamped kernel lives in the measurement build only
     k, n = [int(x) for x in args.shape.split(",")]
     bits, g, m = 4, 128, 1
     nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
@@ -44,12 +41,11 @@ def main():
     for v in [int(x) for x in args.variants.split(",")]:
         waves = ((n + CN[v] - 1) // CN[v]) * NW[v]
         trace = torch.zeros((waves, 8), dtype=torch.int64, device=dev)
-        raw.xbit_debug_set_gemv_trace(trace.data_ptr())
-        raw.xbit_debug_set_gemv_variant(v)
+        opts = _lib.GemvOptions(variant=v, trace=trace.data_ptr())
         for mode in ("cold", "warm"):
             for i in range(12):
                 c = i % copies if mode == "cold" else 0
-                st = lib.xbit_gemv_f16(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc.data_ptr(), qz.data_ptr(), bits, g, m, k, n, 1, sp)
+                st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc.data_ptr(), qz.data_ptr(), bits, g, m, k, n, 1, sp, opts)
                 assert st == 0
             torch.cuda.synchronize()
             t = trace.cpu().numpy()[:, :6].astype(np.float64)
@@ -60,8 +56,6 @@ def main():
                 print("  %-18s min %5.2f  p10 %5.2f  p50 %5.2f  p90 %5.2f  max %5.2f" % (name, d[0], d[len(d) // 10], d[len(d) // 2], d[len(d) * 9 // 10], d[-1]))
             dur = t[:, 3] - t[:, 1]
             print("  per-wave (last MFMA - loads issued): p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(dur, [50, 90, 100])))
-        raw.xbit_debug_set_gemv_trace(None)
-        raw.xbit_debug_set_gemv_variant(-1)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libxbitops_hip.so")
-ABI_VERSION = 1
+TUNING_LIB_PATH = os.path.join(_HERE, "lib", "libxbitops_hip_tuning.so")  # measurement build: tools/ and two A/B tests only
+ABI_VERSION = 2
 
 # every symbol include/xbitops_hip.h declares
 EXPORTS = (
@@ -21,35 +22,45 @@ EXPORTS = (
     "xbit_status_string",
     "xbit_dequant_f16",
     "xbit_gemv_f16",
+    "xbit_gemv_f16_ex",
+    "xbit_gemv_workspace_bytes",
+    "xbit_workspace_reset",
     "xbit_gemv_multi_f16",
     "xbit_profile_enable",
     "xbit_profile_last_ms",
 )
 
 _lib = None
+_tuning = None
 
 
 class XbitLibraryError(RuntimeError):
     pass
 
 
-def load() -> ctypes.CDLL:
-    """Load (once) and type the native library.  Raises XbitLibraryError if it is unusable."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+class GemvOptions(ctypes.Structure):
+    """``xbit_gemv_options`` of include/xbitops_hip.h."""
+
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("split_k", ctypes.c_int32), ("workspace", ctypes.c_void_p),
+                ("workspace_bytes", ctypes.c_uint64), ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32), ("trace", ctypes.c_void_p)]
+
+    def __init__(self, split_k: int = 0, workspace: int = 0, workspace_bytes: int = 0, variant: int = -1, trace: int = 0):
+        super().__init__(ctypes.sizeof(GemvOptions), split_k, workspace or None, workspace_bytes, variant, 0, trace or None)
+
+
+def _typed(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
         raise XbitLibraryError(
-            "xbitops: native library %s not found. Build it with `python -m xbitops_amd.build` "
-            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH
+            "xbitops: native library %s not found. Build it with `python -m xbitops_amd.build%s` "
+            "(hipcc, gfx950). There is no CPU fallback." % (path, " --tuning" if path == TUNING_LIB_PATH else "")
         )
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
     except OSError as e:  # missing libamdhip64 etc.
-        raise XbitLibraryError("xbitops: cannot load %s: %s" % (LIB_PATH, e)) from e
+        raise XbitLibraryError("xbitops: cannot load %s: %s" % (path, e)) from e
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
     if missing:
-        raise XbitLibraryError("xbitops: %s does not export %s" % (LIB_PATH, ", ".join(missing)))
+        raise XbitLibraryError("xbitops: %s does not export %s" % (path, ", ".join(missing)))
 
     lib.xbit_abi_version.restype = ctypes.c_int
     lib.xbit_abi_version.argtypes = []
@@ -60,6 +71,12 @@ def load() -> ctypes.CDLL:
     lib.xbit_dequant_f16.argtypes = [vp, vp, vp, vp, ci, ci, u32, u32, u8, vp]
     lib.xbit_gemv_f16.restype = ci
     lib.xbit_gemv_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, u32, u32, u32, u8, vp]
+    lib.xbit_gemv_f16_ex.restype = ci
+    lib.xbit_gemv_f16_ex.argtypes = [vp, vp, vp, vp, vp, ci, ci, u32, u32, u32, u8, vp, ctypes.POINTER(GemvOptions)]
+    lib.xbit_gemv_workspace_bytes.restype = ctypes.c_uint64
+    lib.xbit_gemv_workspace_bytes.argtypes = [u32, u32]
+    lib.xbit_workspace_reset.restype = ci
+    lib.xbit_workspace_reset.argtypes = []
     lib.xbit_gemv_multi_f16.restype = ci
     lib.xbit_gemv_multi_f16.argtypes = [ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                         ctypes.POINTER(u32), ci, ci, u32, u32, u8, vp]
@@ -69,8 +86,24 @@ def load() -> ctypes.CDLL:
     lib.xbit_profile_last_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     if lib.xbit_abi_version() != ABI_VERSION:
         raise XbitLibraryError("xbitops: ABI version mismatch (library %d, binding %d); rebuild" % (lib.xbit_abi_version(), ABI_VERSION))
-    _lib = lib
     return lib
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the native library.  Raises XbitLibraryError if it is unusable."""
+    global _lib
+    if _lib is None:
+        _lib = _typed(LIB_PATH)
+    return _lib
+
+
+def load_tuning() -> ctypes.CDLL:
+    """The measurement build (same ABI plus ``options.variant`` / ``options.trace``).  Never used by the
+    operators; ``tools/`` and the A/B tests call its C ABI directly."""
+    global _tuning
+    if _tuning is None:
+        _tuning = _typed(TUNING_LIB_PATH)
+    return _tuning
 
 
 def status_string(status: int) -> str:

@@ -1,5 +1,6 @@
 // xbit_capi.hip — the extern "C" surface declared in include/xbitops_hip.h: argument checks,
 // status codes, the common launch function and the per-launch profiling aid.  No kernels here.
+#include <stddef.h>
 #include <string.h>
 
 #include <atomic>
@@ -27,56 +28,106 @@ int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, vo
   }
   if (err != hipSuccess) {
     (void)hipGetLastError();  // clear the sticky error; the caller gets the code
+    mark_workspaces_dirty();  // whatever ran before may have died with scratch in use
     return (int)err;
   }
   return XBIT_OK;
 }
 
-static std::atomic<int> g_gemv_variant{-1};
-static std::atomic<int> g_gemv_split{0};
-int gemv_split_override() { return g_gemv_split.load(std::memory_order_relaxed); }
-
+// ---- split-K scratch -------------------------------------------------------------------------------
 namespace {
-constexpr size_t kAccSlots = (size_t)1 << 18;  // 2 MiB of 64-bit accumulators per stream
+constexpr size_t kStreamSlots = kMaxSplitSlots;       // per (device, stream) buffer for eager launches: 2 MiB
+constexpr size_t kPoolSlots = (size_t)1 << 20;        // per-device pool for captured launches: 8 MiB, never recycled
+struct CapturePool {
+  unsigned long long* base = nullptr;
+  size_t used = 0;
+};
 std::mutex g_ws_mutex;
-std::map<std::pair<int, hipStream_t>, GemvWorkspace> g_ws;  // never freed: lives as long as the process
+std::map<std::pair<int, hipStream_t>, GemvWorkspace> g_ws;  // lives as long as the process
+std::map<int, CapturePool> g_pool;
+std::atomic<bool> g_ws_dirty{false};
+
+// hipMalloc + zero-fill; never called for a capturing stream (allocation inside a capture is not legal)
+unsigned long long* alloc_zeroed(size_t slots) {
+  unsigned long long* ptr = nullptr;
+  bool ok = hipMalloc(reinterpret_cast<void**>(&ptr), slots * sizeof(unsigned long long)) == hipSuccess &&
+            hipMemset(ptr, 0, slots * sizeof(unsigned long long)) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+  }
+  return ptr;
+}
+
+int reset_workspaces_locked(int dev) {
+  hipError_t err = hipDeviceSynchronize();
+  for (auto& kv : g_ws)
+    if (err == hipSuccess && kv.first.first == dev && kv.second.acc) err = hipMemset(kv.second.acc, 0, kv.second.slots * sizeof(unsigned long long));
+  auto it = g_pool.find(dev);
+  if (err == hipSuccess && it != g_pool.end() && it->second.base) err = hipMemset(it->second.base, 0, kPoolSlots * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipDeviceSynchronize();
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)err;
+  }
+  return XBIT_OK;
+}
 }  // namespace
 
-bool gemv_workspace(hipStream_t stream, GemvWorkspace* out) {
+void mark_workspaces_dirty() { g_ws_dirty.store(true, std::memory_order_relaxed); }
+
+bool gemv_workspace(hipStream_t stream, size_t slots, const GemvLaunchOpts& opts, GemvWorkspace* out) {
+  if (slots == 0 || slots > kMaxSplitSlots) return false;
+  if (opts.user_ws) {  // the caller's scratch, or nothing: never mix the two silently
+    if (opts.user_ws_slots < slots) return false;
+    out->acc = opts.user_ws;
+    out->slots = opts.user_ws_slots;
+    return true;
+  }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  std::lock_guard<std::mutex> lock(g_ws_mutex);
-  auto it = g_ws.find({dev, stream});
-  if (it != g_ws.end()) {
-    *out = it->second;
-    return out->acc != nullptr;
-  }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
     (void)hipGetLastError();
-    return false;  // not remembered: a later call outside the capture allocates
+    return false;
   }
-  GemvWorkspace ws;
-  bool ok = hipMalloc(reinterpret_cast<void**>(&ws.acc), kAccSlots * sizeof(unsigned long long)) == hipSuccess &&
-            hipMemsetAsync(ws.acc, 0, kAccSlots * sizeof(unsigned long long), stream) == hipSuccess;
-  if (!ok) {
-    (void)hipGetLastError();
-    if (ws.acc) (void)hipFree(ws.acc);
-    ws = GemvWorkspace{};
-  } else {
-    ws.slots = kAccSlots;
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (cap != hipStreamCaptureStatusNone) {
+    // A captured launch keeps its scratch for as long as the graph may be replayed - on any stream,
+    // beside anything - so it gets a range of its own that is never handed out again.
+    // The pool is created by the first eager split-K launch on the device (or xbit_workspace_reset):
+    // nothing is allocated inside a capture, a capture that comes first runs its launches unsplit.
+    CapturePool& pool = g_pool[dev];
+    if (!pool.base || pool.used + slots > kPoolSlots) return false;
+    out->acc = pool.base + pool.used;
+    out->slots = slots;
+    pool.used += (slots + 15) & ~(size_t)15;  // 128-byte granules: ranges never share a cache line
+    return true;
   }
-  g_ws[{dev, stream}] = ws;  // a failed allocation is remembered too: no retry storm
+  if (g_ws_dirty.exchange(false, std::memory_order_relaxed)) {
+    if (reset_workspaces_locked(dev) != XBIT_OK) {
+      g_ws_dirty.store(true, std::memory_order_relaxed);
+      return false;
+    }
+  }
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;  // another thread may be capturing in global mode
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  CapturePool& pool = g_pool[dev];
+  if (!pool.base) pool.base = alloc_zeroed(kPoolSlots);  // a failure is not remembered: the next launch tries again
+  GemvWorkspace& ws = g_ws[{dev, stream}];
+  if (!ws.acc) {
+    ws.acc = alloc_zeroed(kStreamSlots);
+    ws.slots = ws.acc ? kStreamSlots : 0;
+  }
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (!ws.acc) return false;
   *out = ws;
-  return ok;
+  return true;
 }
-
-static std::atomic<uint64_t*> g_gemv_trace{nullptr};
-int gemv_variant_override() { return g_gemv_variant.load(std::memory_order_relaxed); }
-uint64_t* gemv_trace_buffer() { return g_gemv_trace.load(std::memory_order_relaxed); }
 
 static inline uint32_t packed_rows(uint32_t count, int bits) { return (uint32_t)(((uint64_t)count * (uint64_t)bits + 31u) / 32u); }
 
@@ -105,6 +156,7 @@ const char* xbit_status_string(int status) {
     case XBIT_ERR_GROUPSIZE: return "xbitops: groupsize must be >= 1";
     case XBIT_ERR_SHAPE: return "xbitops: invalid shape (m, k, n must be > 0, n even, sizes within 32-bit packed-word range)";
     case XBIT_ERR_ALIGNMENT: return "xbitops: a device pointer is not aligned to its element size";
+    case XBIT_ERR_UNSUPPORTED: return "xbitops: option not supported by this build of the library (measurement variants need libxbitops_hip_tuning.so)";
     default: break;
   }
   if (status > 0) return hipGetErrorString((hipError_t)status);
@@ -133,13 +185,32 @@ int xbit_dequant_f16(void* out, const void* qweight, const void* scales, const v
   return xbit::launch_dequant(p, bits, static_cast<hipStream_t>(hip_stream));
 }
 
-int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
-                  int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream) {
+int xbit_gemv_f16_ex(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
+                     int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream,
+                     const xbit_gemv_options* options) {
   if (!out || !a) return XBIT_ERR_NULL_POINTER;
   const int st = xbit::check_common(qweight, scales, qzeros, bits, groupsize, k, n);
   if (st != XBIT_OK) return st;
   if (m == 0 || (uint64_t)m * k >= (1ull << 40) || (uint64_t)m * n >= (1ull << 40)) return XBIT_ERR_SHAPE;
   if (((uintptr_t)out & 1u) || ((uintptr_t)a & 1u)) return XBIT_ERR_ALIGNMENT;
+  xbit::GemvLaunchOpts opts;
+  if (options) {
+    // fields beyond the caller's struct_bytes keep their defaults
+    const uint32_t have = options->struct_bytes;
+    auto has = [&](size_t offset, size_t size) { return have >= offset + size; };
+    if (has(offsetof(xbit_gemv_options, split_k), sizeof(int32_t))) opts.split = options->split_k;
+    if (has(offsetof(xbit_gemv_options, workspace_bytes), sizeof(uint64_t)) && options->workspace) {
+      if ((uintptr_t)options->workspace & 7u) return XBIT_ERR_ALIGNMENT;
+      opts.user_ws = static_cast<unsigned long long*>(options->workspace);
+      opts.user_ws_slots = (size_t)(options->workspace_bytes / sizeof(unsigned long long));
+    }
+    if (has(offsetof(xbit_gemv_options, variant), sizeof(int32_t))) opts.variant = options->variant;
+    if (has(offsetof(xbit_gemv_options, trace), sizeof(void*))) opts.trace = static_cast<uint64_t*>(options->trace);
+    if (opts.split < 0 || opts.split > 15) return XBIT_ERR_SHAPE;
+#if !XBIT_TUNING
+    if (opts.variant > 0 || opts.trace) return XBIT_ERR_UNSUPPORTED;
+#endif
+  }
   xbit::GemvParams p;
   p.out = static_cast<uint16_t*>(out);
   p.a = static_cast<const uint16_t*>(a);
@@ -156,11 +227,35 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
   p.bias = add_zero_bias;
   p.tiles = 0;
   p.batches = 0;
-  p.trace = xbit::gemv_trace_buffer();
+  p.trace = opts.trace;
   p.splits = 1;
   p.bps = 0;
   p.acc = nullptr;
-  return xbit::launch_gemv(p, bits, static_cast<hipStream_t>(hip_stream));
+  return xbit::launch_gemv(p, bits, static_cast<hipStream_t>(hip_stream), opts);
+}
+
+int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, int bits,
+                  int groupsize, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream) {
+  return xbit_gemv_f16_ex(out, a, qweight, scales, qzeros, bits, groupsize, m, k, n, add_zero_bias, hip_stream, nullptr);
+}
+
+uint64_t xbit_gemv_workspace_bytes(uint32_t m, uint32_t n) {
+  // split launches run 1 or 4 rows per pass over tiles of 32 or 64 columns: round both up
+  const uint64_t rows = m <= 1 ? 1 : (((uint64_t)m + 3) / 4) * 4, cols = (((uint64_t)n + 63) / 64) * 64;
+  return rows * cols * sizeof(unsigned long long);
+}
+
+int xbit_workspace_reset(void) {
+  int dev = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)err;
+  }
+  std::lock_guard<std::mutex> lock(xbit::g_ws_mutex);
+  xbit::CapturePool& pool = xbit::g_pool[dev];
+  if (!pool.base) pool.base = xbit::alloc_zeroed(xbit::kPoolSlots);  // so that a capture may come before any eager launch
+  return xbit::reset_workspaces_locked(dev);
 }
 
 int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void* const* qweights, const void* const* scales,
@@ -178,7 +273,7 @@ int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void*
   if ((uintptr_t)a & 1u) return XBIT_ERR_ALIGNMENT;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   // one fused launch when the shape allows it (up to 4 rows, the fast path's alignment and size limits) ...
-  bool fused = count >= 2 && m <= 4 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 16 == 0) && xbit::gemv_variant_override() < 0;
+  bool fused = count >= 2 && m <= 4 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 16 == 0);
   for (int j = 0; j < count && fused; ++j)
     fused = ((uint64_t)xbit::packed_rows(k, bits) * ns[j] * 4u < (1ull << 31)) && ((uintptr_t)qweights[j] % 4 == 0);
   if (fused) {
@@ -244,13 +339,5 @@ int xbit_profile_last_ms(float* ms) {
   }
   return XBIT_OK;
 }
-
-/* Tuning hook, deliberately NOT in the public header: selects a GEMV launch-shape variant for
- * sweeps (tools/gemv_sweep.py); -1 restores automatic selection. */
-void xbit_debug_set_gemv_variant(int v) { xbit::g_gemv_variant.store(v, std::memory_order_relaxed); }
-/* Forces the split-K factor of eligible launches (<= 0: automatic; 1: never split). */
-void xbit_debug_set_gemv_split(int splits) { xbit::g_gemv_split.store(splits, std::memory_order_relaxed); }
-/* Device buffer (8 x uint64 per wave) that the stamped measurement build (variants 41+) fills. */
-void xbit_debug_set_gemv_trace(void* device_buffer) { xbit::g_gemv_trace.store(static_cast<uint64_t*>(device_buffer), std::memory_order_relaxed); }
 
 }  // extern "C"

@@ -32,6 +32,7 @@ namespace xbit {
 
 namespace {
 
+#if XBIT_TUNING  // the first-generation VALU-only kernel: measurement builds only (variants 1-7)
 // Streaming (read-once) 16-byte load of packed weights.
 template <bool NT>
 __device__ __forceinline__ uint4 load_w(const void* p) {
@@ -231,6 +232,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1,
   }
 }
 
+#endif  // XBIT_TUNING
+
 // Fully general fallback: any n (even), any groupsize, any k.  One workgroup per output element
 // column-block of 1; slow (re-reads scales per element) but exact.  Used only for shapes the tiled
 // kernel does not take (n % 4 != 0 or groupsize % 32 != 0).
@@ -256,6 +259,7 @@ __global__ void __launch_bounds__(256) gemv_generic_kernel(const GemvParams p, i
   if (threadIdx.x == 0) p.out[(size_t)row * p.n + col] = as_u16((_Float16)s_part[0]);
 }
 
+#if XBIT_TUNING
 template <int BITS, int UB, int LN, int NW, int MT, bool NT>
 int launch_tile(GemvParams p, hipStream_t stream) {
   constexpr int CN = 4 * LN;
@@ -280,12 +284,11 @@ constexpr int max_ub() {
 }
 
 template <int BITS>
-int launch_bits(const GemvParams& p, hipStream_t stream) {
+int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
   constexpr int UBMAX = max_ub<BITS>();
 #define XBIT_SHAPE(UB_, LN_, NW_, NT_) return launch_tile_m<BITS, UB_, LN_, NW_, NT_>(p, stream)
   if (p.groupsize % (32u * UBMAX) == 0) {
     {
-      const int variant = gemv_variant_override();
       switch (variant) {
         case 1: XBIT_SHAPE(UBMAX, 8, 4, false);
         case 2: XBIT_SHAPE(UBMAX, 16, 8, true);
@@ -306,21 +309,24 @@ int launch_bits(const GemvParams& p, hipStream_t stream) {
 #undef XBIT_SHAPE
 }
 
+#endif  // XBIT_TUNING
+
 }  // namespace
 
-int launch_gemv(const GemvParams& p, int bits, hipStream_t stream) {
+int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts) {
   if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
   if (p.m > 65535u * 16u) return XBIT_ERR_SHAPE;
-  const int variant = gemv_variant_override();
   const bool k_ok = (p.k % 8u == 0) && (p.groupsize % 32u == 0) && ((uintptr_t)p.a % 16 == 0);
   // production path: MFMA kernel, any even n
   const bool small = ((uint64_t)p.kw * p.n * 4u < (1ull << 31)) && ((uint64_t)p.m * p.k * 2u < (1ull << 31));
   const bool mfma_ok = k_ok && small && ((uintptr_t)p.qweight % 4 == 0);
-  if (mfma_ok && !(variant >= 0 && variant < 10)) return launch_gemv_mfma(p, bits, stream, variant);
-  // VALU-only (v_dot2c) kernel: 4-bit only, kept for A/B measurements (variants 0..9)
+#if XBIT_TUNING
+  // VALU-only (v_dot2c) kernel: 4-bit only, kept for A/B measurements (variants 1..9)
   const bool dot2_ok = k_ok && bits == 4 && (p.n % 4u == 0) && ((uintptr_t)p.qweight % 16 == 0) &&
                        ((uintptr_t)p.scales % 8 == 0) && p.m <= 65535u;
-  if (dot2_ok && variant >= 0 && variant < 10) return launch_bits<4>(p, stream);
+  if (dot2_ok && opts.variant >= 1 && opts.variant < 10) return launch_bits<4>(p, stream, opts.variant);
+#endif
+  if (mfma_ok) return launch_gemv_mfma(p, bits, stream, opts);
   // everything else: exact but slow
   if (p.m > 65535u) return XBIT_ERR_SHAPE;
   dim3 grid(p.n, p.m), block(256);

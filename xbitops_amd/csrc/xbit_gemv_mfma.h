@@ -727,16 +727,20 @@ int launch_multi_bits(const GemvMultiParams& p, hipStream_t stream) {
 }
 
 template <int BITS>
-int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
+int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts) {
   constexpr int UBMAX = max_ub<BITS>();
   const uint32_t kblocks = (p.k + 31) / 32;
   int cpl = pick_cpl(p.n);
+  int variant = (XBIT_TUNING && opts.variant > 0) ? opts.variant : -1;  // the production library has no variants
+#if XBIT_TUNING
   if (variant >= 112 && variant <= 114) {  // sweep hook, any M: force the tile width of the default path (32/48/64 columns)
     cpl = variant - 110;
     variant = -1;
   }
+#endif
   if (p.groupsize % (32u * UBMAX) == 0) {
-    if (variant >= 0 && p.m == 1) {  // tuning hooks (M = 1): tools/gemv_sweep.py, tools/README.md
+#if XBIT_TUNING
+    if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
         case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
         case 106: return launch_la<BITS, UBMAX, 3, 16, 8, 0, lookahead_for<BITS>()>(p, stream);  // same launch, default unpack
@@ -801,19 +805,20 @@ int launch_bits(const GemvParams& p, hipStream_t stream, int variant) {
         }
       }
     }
+#endif  // XBIT_TUNING
     // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
     {
-      SplitPlan plan = plan_split(p, UBMAX, gemv_split_override());
-      if ((variant == 202 || variant == 205) && plan.splits >= 2) {  // sweep hook: force the tile width
+      SplitPlan plan = plan_split(p, UBMAX, opts.split);
+      if ((variant == 202 || variant == 205) && plan.splits >= 2) {  // sweep hook (tuning builds): force the tile width
         plan.cpl = variant == 202 ? 2 : 4;
-      } else if (variant >= 0) {
-        plan.splits = 0;  // another tuning variant was asked for
+      } else if (variant > 0) {
+        plan.splits = 0;  // another measurement variant was asked for
       }
       if (plan.splits >= 2) {
         const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
         const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
         GemvWorkspace ws;
-        if (slots <= ((size_t)1 << 18) && gemv_workspace(stream, &ws) && slots <= ws.slots) return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
+        if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
       }
     }
     // Few tiles (e.g. the 8192x3584 shard of a 70B FFN on 8 GPUs: 112 tiles of 32 columns; 4096x4096):

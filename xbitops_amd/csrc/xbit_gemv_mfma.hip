@@ -5,13 +5,13 @@
 
 namespace xbit {
 
-int launch_gemv_mfma_b2(const GemvParams& p, hipStream_t stream, int variant);
-int launch_gemv_mfma_b3(const GemvParams& p, hipStream_t stream, int variant);
-int launch_gemv_mfma_b4(const GemvParams& p, hipStream_t stream, int variant);
-int launch_gemv_mfma_b5(const GemvParams& p, hipStream_t stream, int variant);
-int launch_gemv_mfma_b6(const GemvParams& p, hipStream_t stream, int variant);
-int launch_gemv_mfma_b7(const GemvParams& p, hipStream_t stream, int variant);
-int launch_gemv_mfma_b8(const GemvParams& p, hipStream_t stream, int variant);
+int launch_gemv_mfma_b2(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
+int launch_gemv_mfma_b3(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
+int launch_gemv_mfma_b4(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
+int launch_gemv_mfma_b5(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
+int launch_gemv_mfma_b6(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
+int launch_gemv_mfma_b7(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
+int launch_gemv_mfma_b8(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
 
 int launch_gemv_multi_b2(const GemvMultiParams& p, hipStream_t stream);
 int launch_gemv_multi_b3(const GemvMultiParams& p, hipStream_t stream);
@@ -21,15 +21,15 @@ int launch_gemv_multi_b6(const GemvMultiParams& p, hipStream_t stream);
 int launch_gemv_multi_b7(const GemvMultiParams& p, hipStream_t stream);
 int launch_gemv_multi_b8(const GemvMultiParams& p, hipStream_t stream);
 
-int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int variant) {
+int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts) {
   switch (bits) {
-    case 2: return launch_gemv_mfma_b2(p, stream, variant);
-    case 3: return launch_gemv_mfma_b3(p, stream, variant);
-    case 4: return launch_gemv_mfma_b4(p, stream, variant);
-    case 5: return launch_gemv_mfma_b5(p, stream, variant);
-    case 6: return launch_gemv_mfma_b6(p, stream, variant);
-    case 7: return launch_gemv_mfma_b7(p, stream, variant);
-    case 8: return launch_gemv_mfma_b8(p, stream, variant);
+    case 2: return launch_gemv_mfma_b2(p, stream, opts);
+    case 3: return launch_gemv_mfma_b3(p, stream, opts);
+    case 4: return launch_gemv_mfma_b4(p, stream, opts);
+    case 5: return launch_gemv_mfma_b5(p, stream, opts);
+    case 6: return launch_gemv_mfma_b6(p, stream, opts);
+    case 7: return launch_gemv_mfma_b7(p, stream, opts);
+    case 8: return launch_gemv_mfma_b8(p, stream, opts);
     default: return XBIT_ERR_BITS;
   }
 }

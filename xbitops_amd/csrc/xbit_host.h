@@ -52,15 +52,28 @@ struct GemvMultiParams : GemvParams {
   uint16_t* multi_out[kMaxMulti];
 };
 
-// Per-(device, stream) scratch for split-K launches: launches on one stream run in order, so they
-// can share it; different streams get their own.  Allocated on first use and kept.
+// Split-K scratch (64-bit accumulators, zero between launches; see include/xbitops_hip.h "State").
 struct GemvWorkspace {
   unsigned long long* acc = nullptr;
   size_t slots = 0;
 };
-// false: no workspace for this stream (allocation failed, or the first use would fall inside a
-// stream capture, where allocation is not allowed) - the caller then launches without split-K.
-bool gemv_workspace(hipStream_t stream, GemvWorkspace* ws);
+
+// Host-side choices of one GEMV call (never passed to a kernel).
+struct GemvLaunchOpts {
+  int split = 0;                        // 0 automatic, 1 never, 2..15 forced
+  int variant = -1;                     // measurement variant (XBIT_TUNING builds), <= 0: production launch
+  unsigned long long* user_ws = nullptr;  // caller-owned scratch, or nullptr
+  size_t user_ws_slots = 0;
+  uint64_t* trace = nullptr;            // stamped measurement build only
+};
+
+// Scratch for a split-K launch of `slots` accumulators on `stream`: the caller's if `opts` has one
+// that is large enough, else the library's (per-stream buffer for eager launches, a private pool
+// range inside a stream capture).  false = none available: launch unsplit.
+bool gemv_workspace(hipStream_t stream, size_t slots, const GemvLaunchOpts& opts, GemvWorkspace* ws);
+constexpr size_t kMaxSplitSlots = (size_t)1 << 18;  // largest launch that may be split (2 MiB of accumulators)
+// A failed launch may have left library scratch dirty: re-zero it before the next split-K launch.
+void mark_workspaces_dirty();
 
 // thread-local profiling state (xbit_profile_enable / xbit_profile_last_ms)
 struct ProfileState {
@@ -82,14 +95,16 @@ int launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, 
 }
 
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
-int launch_gemv(const GemvParams& p, int bits, hipStream_t stream);                        // dispatcher (xbit_gemv.hip)
-int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, int variant);     // xbit_gemv_mfma.hip
+int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);          // dispatcher (xbit_gemv.hip)
+int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);     // xbit_gemv_mfma.hip
 // fused launch over p.multi_* (M = 1); XBIT_ERR_SHAPE when the shape is not eligible (caller then launches one by one)
 int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
 
-// tuning hooks (tools/ only): variant < 0 = automatic; trace buffer for the stamped build
-int gemv_variant_override();
-int gemv_split_override();  // <= 0: automatic
-uint64_t* gemv_trace_buffer();
+// XBIT_TUNING builds (libxbitops_hip_tuning.so) additionally hold the measurement variants: launch
+// shapes, ablations, the stamped kernel and the first-generation VALU-only kernel.  The production
+// library contains none of them.
+#ifndef XBIT_TUNING
+#define XBIT_TUNING 0
+#endif
 
 }  // namespace xbit

@@ -80,7 +80,7 @@ def gemv_errors(y: np.ndarray, golden: np.ndarray) -> int:
     """Number of elements the reference harness would flag (gemv_w4a16.cu:396-412)."""
     v1, ref = y.astype(np.float32).ravel(), golden.astype(np.float32).ravel()
     with np.errstate(divide="ignore", invalid="ignore"):
-        rel = (ref / v1 > 1.001) | (v1 / ref > 1.001)
+        rel = (np.abs(ref / v1) > 1.001) | (np.abs(v1 / ref) > 1.001)  # abs() as the reference: a sign flip is an error
     return int((rel & (np.abs(ref - v1) > 4e-4)).sum())
 
 

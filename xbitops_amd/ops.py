@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["dequant", "gemv", "gemv_multi", "GemvPlan"]
+__all__ = ["dequant", "gemv", "gemv_ex", "gemv_multi", "GemvPlan"]
 
 
 def _check_input(t: torch.Tensor, name: str) -> None:
@@ -133,6 +133,20 @@ def dequant(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g
 def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, groupsize: int, bits: int,
          in_features: int, add_zero_bias: int) -> torch.Tensor:
     """``input_a[B, K]`` or ``[B, S, K]`` (fp16) times the dequantised weight -> ``[B, (S,) N]``."""
+    return gemv_ex(input_a, qweight, scales, qzeros, groupsize, bits, in_features, add_zero_bias)
+
+
+def gemv_ex(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, groupsize: int, bits: int,
+            in_features: int, add_zero_bias: int, *, split_k: int = 0, workspace: torch.Tensor = None, variant: int = -1) -> torch.Tensor:
+    """:func:`gemv` with the per-call options of ``xbit_gemv_f16_ex`` (include/xbitops_hip.h):
+
+    * ``split_k``: 0 = the library chooses, 1 = never split K, 2..15 = split K that many ways where the
+      shape allows (same result up to the fp32 summation order);
+    * ``workspace``: a zero-filled device tensor of at least ``xbit_gemv_workspace_bytes(M, N)`` bytes that
+      this launch alone uses as split-K scratch (it is zero again afterwards); default: library-managed;
+    * ``variant`` > 0: a measurement variant — served by the TUNING build of the library
+      (``python -m xbitops_amd.build --tuning``), never by the production one.
+    """
     groupsize, bits, in_features = int(groupsize), int(bits), int(in_features)
     bias = add_zero_bias_check(add_zero_bias)
     _check_input(input_a, "input_a")
@@ -143,7 +157,7 @@ def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
         raise RuntimeError("input_a must be float16")
     if input_a.dim() not in (2, 3) or input_a.size(-1) != in_features:
         raise RuntimeError("input_a must be [B, in_features] or [B, S, in_features], got %s" % (tuple(input_a.shape),))
-    lib = _lib.load()
+    lib = _lib.load_tuning() if variant > 0 else _lib.load()
     n = qweight.size(1)
     shape = [input_a.size(0), n]  # dq_torch_ops.cc:59-64
     mat_m = input_a.size(0)
@@ -153,11 +167,21 @@ def gemv(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
     ori_dtype = scales.dtype
     f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales  # :65-69
     idx = qweight.device.index
+    opts = None
+    if split_k or workspace is not None or variant > 0:
+        if workspace is not None and (not workspace.is_cuda or workspace.device != qweight.device or not workspace.is_contiguous()):
+            raise RuntimeError("workspace must be a contiguous tensor on the weights' device")
+        opts = _lib.GemvOptions(split_k=int(split_k), workspace=workspace.data_ptr() if workspace is not None else 0,
+                                workspace_bytes=workspace.numel() * workspace.element_size() if workspace is not None else 0, variant=int(variant))
     with _on_device(idx):
         out = torch.empty(shape, dtype=torch.float16, device=qweight.device)
         if mat_m > 0:
-            st = lib.xbit_gemv_f16(out.data_ptr(), input_a.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(),
-                                   bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx))
+            if opts is None:
+                st = lib.xbit_gemv_f16(out.data_ptr(), input_a.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(),
+                                       bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx))
+            else:
+                st = lib.xbit_gemv_f16_ex(out.data_ptr(), input_a.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(),
+                                          bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx), opts)
             _lib.check(st, "XbitOps.gemv")
     return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :74-76
 
