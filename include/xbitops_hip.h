@@ -131,6 +131,22 @@ uint64_t xbit_gemv_workspace_bytes(uint32_t m, uint32_t n);
  * Returns 0 or a positive hipError_t. */
 int xbit_workspace_reset(void);
 
+/* Act-order ("desc_act") checkpoints: the group of row k is g_idx[k] instead of k / groupsize.
+ * Counterpart of the reference's vecquant4matmul_g_cuda / VecQuant4MatMulKernel_G
+ * (/root/reference/src/cu/quant_cuda_kernel.cu:221-336, compiled out there by `#if 0`), for bits 2..8
+ * and with add_zero_bias in place of that kernel's hard-wired "+ 1" (:299-300):
+ *     W[k,n] = fp16( q[k,n]*s[g,n] - fp16((z[g,n] + add_zero_bias)*s[g,n]) ),  g = g_idx[k]
+ *   g_idx   int32 [k], device, values in [0, groups)  (larger values are clamped to groups - 1)
+ *   groups  rows of `scales` [groups, n] and `qzeros` [groups, ceil(n*bits/32)]
+ * These are the GENERAL entries (any g_idx).  When every group has the same number of rows — what
+ * GPTQ act-order produces — sort the packed rows by group once at load time and call the ordinary
+ * entry points on the sorted weight with the activation permuted alike (xbitops_amd.packing.
+ * sort_rows_by_group; xbitops_amd.linear.QuantLinear does it): that runs at the ordinary kernels' speed. */
+int xbit_gemv_gidx_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, const void* g_idx,
+                       int bits, uint32_t groups, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream);
+int xbit_dequant_gidx_f16(void* out, const void* qweight, const void* scales, const void* qzeros, const void* g_idx, int bits,
+                          uint32_t groups, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream);
+
 /* Extension (not in the reference): one activation against `count` (1..4) weight sets that share k,
  * bits and groupsize - q/k/v or gate/up of a decoder layer - in ONE launch when the shape allows
  * (m <= 4 and the fast path's alignment rules), otherwise as `count` xbit_gemv_f16 launches; results

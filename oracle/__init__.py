@@ -136,6 +136,49 @@ def gemv(act, qweight, scales, qzeros, groupsize: int, bits: int, in_features: i
     return out.view(np.float16)
 
 
+def _i32p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def dequant_gidx(qweight, scales, qzeros, g_idx, bits: int, in_features: int, add_zero_bias: int = 0, mode: int = RNE) -> np.ndarray:
+    """W[K, N] float16 with the group of row k given by ``g_idx[k]`` (act-order; quant_cuda_kernel.cu:257-336)."""
+    qw, sc, qz = _prep(qweight, scales, qzeros)
+    gi = np.ascontiguousarray(g_idx, dtype=np.int32)
+    assert gi.shape == (in_features,) and gi.min() >= 0 and gi.max() < sc.shape[0]
+    n = qw.shape[1]
+    out = np.empty((in_features, n), np.uint16)
+    lib().xo_dequant_gidx(_u16p(out), _u32p(qw), _u16p(sc), _u32p(qz), _i32p(gi), ctypes.c_int(bits), ctypes.c_uint32(in_features),
+                          ctypes.c_uint32(n), ctypes.c_int(add_zero_bias), ctypes.c_int(mode))
+    return out.view(np.float16)
+
+
+def gemv_gidx(act, qweight, scales, qzeros, g_idx, bits: int, in_features: int, add_zero_bias: int = 0, mode: int = RNE) -> np.ndarray:
+    """y[M, N] float16 = fp16(sum_k a[m,k] * W[k,n]) with W = dequant_gidx(mode), double accumulation."""
+    qw, sc, qz = _prep(qweight, scales, qzeros)
+    gi = np.ascontiguousarray(g_idx, dtype=np.int32)
+    assert gi.shape == (in_features,) and gi.min() >= 0 and gi.max() < sc.shape[0]
+    a = np.ascontiguousarray(act, dtype=np.float16).reshape(-1, in_features).view(np.uint16)
+    n = qw.shape[1]
+    out = np.empty((a.shape[0], n), np.uint16)
+    lib().xo_gemv_gidx(_u16p(out), _u16p(a), _u32p(qw), _u16p(sc), _u32p(qz), _i32p(gi), ctypes.c_int(bits), ctypes.c_uint32(a.shape[0]),
+                       ctypes.c_uint32(in_features), ctypes.c_uint32(n), ctypes.c_int(add_zero_bias), ctypes.c_int(mode))
+    return out.view(np.float16)
+
+
+def gemv_w4_transposed(act, qweight_t, scales_t, qzeros_t, groupsize: int, in_features: int, add_zero_bias: int = 0, mode: int = RNE) -> np.ndarray:
+    """y[M, N] for the transposed 4-bit layout of the reference's gemv_NT (gemv_w4a16_nt.cu:64-159):
+    qweight_t [N, ceil(K/8)], scales_t [N, G], qzeros_t [N/8, G]."""
+    qw = np.ascontiguousarray(qweight_t).view(np.uint32)
+    sc = np.ascontiguousarray(scales_t, dtype=np.float16).view(np.uint16)
+    qz = np.ascontiguousarray(qzeros_t).view(np.uint32)
+    n = qw.shape[0]
+    a = np.ascontiguousarray(act, dtype=np.float16).reshape(-1, in_features).view(np.uint16)
+    out = np.empty((a.shape[0], n), np.uint16)
+    lib().xo_gemv_w4_transposed(_u16p(out), _u16p(a), _u32p(qw), _u16p(sc), _u32p(qz), ctypes.c_int(groupsize), ctypes.c_uint32(a.shape[0]),
+                                ctypes.c_uint32(in_features), ctypes.c_uint32(n), ctypes.c_int(add_zero_bias), ctypes.c_int(mode))
+    return out.view(np.float16)
+
+
 def matvec_f16(act, w) -> np.ndarray:
     """y[M, N] float16 = fp16(a @ W) for a dequantised fp16 W[K, N] (double accumulation)."""
     wv = np.ascontiguousarray(w, dtype=np.float16).view(np.uint16)

@@ -216,6 +216,74 @@ void xo_gemv(uint16_t* out, const uint16_t* a, const uint32_t* qweight, const ui
   }
 }
 
+/* ---- act-order ("desc_act") checkpoints: the group of row k is g_idx[k], not k / groupsize.
+ * Restates /root/reference/src/cu/quant_cuda_kernel.cu:257-336 (VecQuant4MatMulKernel_G, compiled out
+ * there by `#if 0` at :220): per k it reads  g = g_idx[k]  (:293-294), the scale  scales[g*width + w]
+ * (:295-296) and the zero-point nibble of (g, w) plus one (:299-300), and forms
+ *     W = hfma(half(q), scale, hmul(-scale, half(z + 1)))                     (:299-300, :306-309)
+ * i.e. the same single-rounded product-sum as the contiguous-group kernels with the group looked up
+ * per row.  The "+ 1" is that kernel's hard-wired GPTQ convention; here it is add_zero_bias as in the
+ * two registered ops.  The reference accumulates in fp16 (:306-312); the checker keeps the op
+ * semantics "dequantise, then multiply" with a wide accumulator, as xo_gemv does.  Any bit-width. */
+void xo_dequant_gidx(uint16_t* out, const uint32_t* qweight, const uint16_t* scales, const uint32_t* qzeros, const int32_t* g_idx,
+                     int bits, uint32_t k, uint32_t n, int add_zero_bias, int mode) {
+  const uint32_t kw = kwords(k, bits), zw = kwords(n, bits);
+#pragma omp parallel for schedule(static)
+  for (int64_t col = 0; col < (int64_t)n; ++col)
+    for (uint32_t r = 0; r < k; ++r) {
+      const uint32_t g = (uint32_t)g_idx[r];
+      const uint16_t s = scales[(size_t)g * n + col];
+      const int z = (int)stream_get(qzeros + (size_t)g * zw, 1, (uint64_t)col, bits, zw) + add_zero_bias;
+      const uint16_t zs = hmul(int_to_half(z, mode), s, mode);
+      const uint32_t q = stream_get(qweight + col, n, r, bits, kw);
+      out[(size_t)r * n + col] = hfma_negc(int_to_half((int)q, mode), s, zs, mode);
+    }
+}
+
+void xo_gemv_gidx(uint16_t* out, const uint16_t* a, const uint32_t* qweight, const uint16_t* scales, const uint32_t* qzeros,
+                  const int32_t* g_idx, int bits, uint32_t m, uint32_t k, uint32_t n, int add_zero_bias, int mode) {
+  const uint32_t kw = kwords(k, bits), zw = kwords(n, bits);
+#pragma omp parallel for schedule(static)
+  for (int64_t col = 0; col < (int64_t)n; ++col)
+    for (uint32_t i = 0; i < m; ++i) {
+      double acc = 0.0;
+      for (uint32_t r = 0; r < k; ++r) {
+        const uint32_t g = (uint32_t)g_idx[r];
+        const uint16_t s = scales[(size_t)g * n + col];
+        const int z = (int)stream_get(qzeros + (size_t)g * zw, 1, (uint64_t)col, bits, zw) + add_zero_bias;
+        const uint16_t zs = hmul(int_to_half(z, mode), s, mode);
+        const uint32_t q = stream_get(qweight + col, n, r, bits, kw);
+        acc += (double)h2f(a[(size_t)i * k + r]) * (double)h2f(hfma_negc(int_to_half((int)q, mode), s, zs, mode));
+      }
+      out[(size_t)i * n + col] = d2h_rne(acc);
+    }
+}
+
+/* ---- transposed 4-bit layout of the reference's experimental gemv_NT
+ * (/root/reference/src/cu/gemv_w4a16_nt.cu:64-159): qweight_t [N, ceil(K/8)] (a column's k-stream is
+ * contiguous: `inB + n*weight_rows + k/8`, :104), scales_t [N, G] (`scales + g + n*group_nums`, :86,
+ * :125), qzeros_t [N/8, G] with the nibble of column n at bits 4*(n%8) (`qzeros + n/8*group_nums + g`,
+ * `>> 8*(tidy%4)` and `+4` for the column pair 2*tidy, 2*tidy+1, :87-89).  W = hfma(s, q, -(z*s))
+ * (:145-148; no zero-point bias in that kernel: add_zero_bias = 0 reproduces it). */
+void xo_gemv_w4_transposed(uint16_t* out, const uint16_t* a, const uint32_t* qweight_t, const uint16_t* scales_t,
+                           const uint32_t* qzeros_t, int groupsize, uint32_t m, uint32_t k, uint32_t n, int add_zero_bias, int mode) {
+  const uint32_t weight_rows = (k + 7) / 8, groups = (k + (uint32_t)groupsize - 1) / (uint32_t)groupsize;
+#pragma omp parallel for schedule(static)
+  for (int64_t col = 0; col < (int64_t)n; ++col)
+    for (uint32_t i = 0; i < m; ++i) {
+      double acc = 0.0;
+      for (uint32_t r = 0; r < k; ++r) {
+        const uint32_t g = r / (uint32_t)groupsize;
+        const uint16_t s = scales_t[(size_t)col * groups + g];
+        const int z = (int)((qzeros_t[(size_t)(col / 8) * groups + g] >> (4 * (col % 8))) & 0xFu) + add_zero_bias;
+        const uint16_t zs = hmul(int_to_half(z, mode), s, mode);
+        const uint32_t q = (qweight_t[(size_t)col * weight_rows + r / 8] >> (4 * (r % 8))) & 0xFu;
+        acc += (double)h2f(a[(size_t)i * k + r]) * (double)h2f(hfma_negc(int_to_half((int)q, mode), s, zs, mode));
+      }
+      out[(size_t)i * n + col] = d2h_rne(acc);
+    }
+}
+
 /* y = a . W for an already dequantised fp16 W[k,n] (used to turn a reference-simulator W into
  * the reference-side GEMV result; double accumulation, RNE store). */
 void xo_matvec_f16(uint16_t* out, const uint16_t* a, const uint16_t* w, uint32_t m, uint32_t k, uint32_t n) {

@@ -678,3 +678,30 @@ def test_split_k_overflow_and_nan_follow_the_unsplit_result(cuda_device):
     a = torch.from_numpy(act).to(cuda_device)
     got = ops.gemv(a, qw, scd, qz, 128, 4, k, 1).cpu().numpy()
     assert np.isnan(got).all()
+
+
+def test_split_k_cancellation_between_k_ranges(cuda_device):
+    """partial sums of opposite sign in different K ranges.  Inside the fixed-point range
+    (|partial| < 2^19) the split kernel adds them exactly, so a huge +/- pair cancels to the small
+    finite total the unsplit fp32 sum gives; beyond it the documented contract is saturation."""
+    from xbitops_amd import ops
+
+    k, n, g = 16384, 256, 128
+    q = np.full((k, n), 7, np.uint8)
+    q[5, :] = 9          # one weight differs: total = W(9) - W(7) ... times its activation
+    z = np.full((k // g, n), 3, np.uint8)
+    act = np.ones((1, k), np.float16)
+    act[0, k // 2:] = -1.0   # first K half sums to +8192 * W, second half to -8192 * W
+    for scale, want_finite in ((8.0, True), (32.0, False)):   # partials of 2^18 (in range) and 2^20 (saturate)
+        sc = np.full((k // g, n), scale, np.float16)
+        qw, qz = packing.pack_qweight(q, 4), packing.pack_qzeros(z, 4)
+        y_ref = oracle.gemv(act, qw, sc, qz, g, 4, k, 0, oracle.RNE)
+        assert np.all(y_ref.astype(np.float32) == 2 * scale)  # (9 - 3) * s - (7 - 3) * s: everything else cancels
+        a, qwd, scd, qzd = (torch.from_numpy(x).to(cuda_device) for x in (act, qw, sc, qz))
+        y1 = ops.gemv_ex(a, qwd, scd, qzd, g, 4, k, 0, split_k=1).cpu().numpy()
+        y2 = ops.gemv_ex(a, qwd, scd, qzd, g, 4, k, 0, split_k=2).cpu().numpy()
+        assert np.array_equal(y1, y_ref)  # unsplit: fp32 accumulation of exactly representable terms
+        if want_finite:
+            assert np.array_equal(y2, y_ref)
+        else:
+            assert np.isnan(y2.astype(np.float32)).all()  # +2^20 in one range, -2^20 in the other: both saturate

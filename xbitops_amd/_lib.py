@@ -25,6 +25,8 @@ EXPORTS = (
     "xbit_gemv_f16_ex",
     "xbit_gemv_workspace_bytes",
     "xbit_workspace_reset",
+    "xbit_gemv_gidx_f16",
+    "xbit_dequant_gidx_f16",
     "xbit_gemv_multi_f16",
     "xbit_profile_enable",
     "xbit_profile_last_ms",
@@ -77,6 +79,10 @@ def _typed(path: str) -> ctypes.CDLL:
     lib.xbit_gemv_workspace_bytes.argtypes = [u32, u32]
     lib.xbit_workspace_reset.restype = ci
     lib.xbit_workspace_reset.argtypes = []
+    lib.xbit_gemv_gidx_f16.restype = ci
+    lib.xbit_gemv_gidx_f16.argtypes = [vp, vp, vp, vp, vp, vp, ci, u32, u32, u32, u32, u8, vp]
+    lib.xbit_dequant_gidx_f16.restype = ci
+    lib.xbit_dequant_gidx_f16.argtypes = [vp, vp, vp, vp, vp, ci, u32, u32, u32, u8, vp]
     lib.xbit_gemv_multi_f16.restype = ci
     lib.xbit_gemv_multi_f16.argtypes = [ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                         ctypes.POINTER(u32), ci, ci, u32, u32, u8, vp]

@@ -18,13 +18,24 @@ ProfileState& profile_state() {
 }
 
 int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, void** args) {
+  return launch_raw_dynamic(kernel, grid, block, 0, stream, args);
+}
+
+int launch_raw_dynamic(const void* kernel, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t stream, void** args) {
   ProfileState& ps = profile_state();
-  hipError_t err;
+  hipError_t err = hipSuccess;
+  if (dynamic_lds > (size_t)(32 << 10)) {  // statics + dynamic may pass the 64 KB default: allow the chip's 160 KB
+    err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
+    if (err != hipSuccess) {
+      (void)hipGetLastError();
+      return (int)err;
+    }
+  }
   if (ps.enabled) {
-    err = hipExtLaunchKernel(kernel, grid, block, args, 0, stream, ps.start, ps.stop, 0);
+    err = hipExtLaunchKernel(kernel, grid, block, args, dynamic_lds, stream, ps.start, ps.stop, 0);
     ps.pending = (err == hipSuccess);
   } else {
-    err = hipLaunchKernel(kernel, grid, block, args, 0, stream);
+    err = hipLaunchKernel(kernel, grid, block, args, dynamic_lds, stream);
   }
   if (err != hipSuccess) {
     (void)hipGetLastError();  // clear the sticky error; the caller gets the code
@@ -256,6 +267,47 @@ int xbit_workspace_reset(void) {
   xbit::CapturePool& pool = xbit::g_pool[dev];
   if (!pool.base) pool.base = xbit::alloc_zeroed(xbit::kPoolSlots);  // so that a capture may come before any eager launch
   return xbit::reset_workspaces_locked(dev);
+}
+
+static int gidx_params(xbit::GemvGidxParams* p, void* out, const void* a, const void* qweight, const void* scales, const void* qzeros,
+                       const void* g_idx, int bits, uint32_t groups, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias) {
+  if (!out || !g_idx) return XBIT_ERR_NULL_POINTER;
+  const int st = xbit::check_common(qweight, scales, qzeros, bits, 1, k, n);
+  if (st != XBIT_OK) return st;
+  if (groups == 0 || groups > 65535u) return XBIT_ERR_GROUPSIZE;
+  if (((uintptr_t)out & 1u) || ((uintptr_t)g_idx & 3u) || ((uintptr_t)a & 1u)) return XBIT_ERR_ALIGNMENT;
+  p->out = static_cast<uint16_t*>(out);
+  p->a = static_cast<const uint16_t*>(a);
+  p->qweight = static_cast<const uint32_t*>(qweight);
+  p->scales = static_cast<const uint16_t*>(scales);
+  p->qzeros = static_cast<const uint32_t*>(qzeros);
+  p->g_idx = static_cast<const int32_t*>(g_idx);
+  p->m = m;
+  p->k = k;
+  p->n = n;
+  p->kw = xbit::packed_rows(k, bits);
+  p->groups = groups;
+  p->zw = xbit::packed_rows(n, bits);
+  p->bias = add_zero_bias;
+  return XBIT_OK;
+}
+
+int xbit_gemv_gidx_f16(void* out, const void* a, const void* qweight, const void* scales, const void* qzeros, const void* g_idx,
+                       int bits, uint32_t groups, uint32_t m, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream) {
+  if (!a) return XBIT_ERR_NULL_POINTER;
+  if (m == 0 || (uint64_t)m * k >= (1ull << 40) || (uint64_t)m * n >= (1ull << 40)) return XBIT_ERR_SHAPE;
+  xbit::GemvGidxParams p;
+  const int st = gidx_params(&p, out, a, qweight, scales, qzeros, g_idx, bits, groups, m, k, n, add_zero_bias);
+  if (st != XBIT_OK) return st;
+  return xbit::launch_gemv_gidx(p, bits, static_cast<hipStream_t>(hip_stream));
+}
+
+int xbit_dequant_gidx_f16(void* out, const void* qweight, const void* scales, const void* qzeros, const void* g_idx, int bits,
+                          uint32_t groups, uint32_t k, uint32_t n, uint8_t add_zero_bias, void* hip_stream) {
+  xbit::GemvGidxParams p;
+  const int st = gidx_params(&p, out, nullptr, qweight, scales, qzeros, g_idx, bits, groups, 0, k, n, add_zero_bias);
+  if (st != XBIT_OK) return st;
+  return xbit::launch_dequant_gidx(p, bits, static_cast<hipStream_t>(hip_stream));
 }
 
 int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void* const* qweights, const void* const* scales,

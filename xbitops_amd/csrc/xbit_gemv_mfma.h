@@ -478,8 +478,15 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       // half the smallest fp16 spacing.  The thread that completes the count converts and stores,
       // then clears the slot for the next launch.  Layout: bits 0-51 sum of (v + 2^47), 52-55
       // arrivals, 56-59 arrivals with a partial sum >= 2^19 or +Inf, 60-63 with one <= -2^19 or -Inf
-      // (a NaN counts in both): the result is then +Inf, -Inf or, with both kinds present, NaN - what
-      // an fp16 store of the unsplit sum would give (65504 is the largest finite fp16).
+      // (a NaN counts in both): the result is then +Inf, -Inf or, with both kinds present, NaN.
+      // Contract (tests: test_split_k_overflow..., test_split_k_cancellation...): while every K-range
+      // partial sum stays inside +-2^19 (8 x the largest finite fp16) the split result is the exact
+      // sum of the partials rounded once - cancellation between ranges included.  A partial outside
+      // that range saturates: the output is +-Inf (NaN if both signs saturate) even where the unsplit
+      // fp32 sum would have cancelled back into range - a case that needs |W * a| ~ 10^2 per term over
+      // thousands of terms with an fp16-representable total.  Partials are quantised to 2^-28
+      // (<= 15 * 2^-29 of error in total: below half an ulp of every normal fp16, a quarter of the
+      // smallest subnormal's spacing).
       if (valid) {
         unsigned long long* slot = p.acc + ((size_t)blockIdx.y * p.tiles + tile_g) * (size_t)(MT * CN) + e;
         const bool fin = __builtin_fabsf(sum) < 524288.0f;  // 2^19; false for NaN / Inf too

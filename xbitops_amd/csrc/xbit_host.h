@@ -52,6 +52,17 @@ struct GemvMultiParams : GemvParams {
   uint16_t* multi_out[kMaxMulti];
 };
 
+// Act-order launches (xbit_gidx.hip): the group of row k is g_idx[k].
+struct GemvGidxParams {
+  uint16_t* out;            // fp16 [m, n] (gemv) or [k, n] (dequant)
+  const uint16_t* a;        // fp16 [m, k] (gemv only)
+  const uint32_t* qweight;  // [kw, n]
+  const uint16_t* scales;   // fp16 [groups, n]
+  const uint32_t* qzeros;   // [groups, zw]
+  const int32_t* g_idx;     // [k], values in [0, groups)
+  uint32_t m, k, n, kw, groups, zw, bias;
+};
+
 // Split-K scratch (64-bit accumulators, zero between launches; see include/xbitops_hip.h "State").
 struct GemvWorkspace {
   unsigned long long* acc = nullptr;
@@ -85,6 +96,8 @@ ProfileState& profile_state();
 
 // Every launch goes through here; returns 0 or a positive hipError_t (never aborts).
 int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, void** args);
+// ... with `dynamic_lds` bytes of dynamic LDS (the 64 KB default limit is raised for the kernel when needed)
+int launch_raw_dynamic(const void* kernel, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t stream, void** args);
 
 // Launch `kernel<<<grid, block, 0, stream>>>(args...)`.
 template <typename... KArgs, typename... Args>
@@ -99,6 +112,8 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);     // xbit_gemv_mfma.hip
 // fused launch over p.multi_* (M = 1); XBIT_ERR_SHAPE when the shape is not eligible (caller then launches one by one)
 int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
+int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);     // xbit_gidx.hip
+int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);
 
 // XBIT_TUNING builds (libxbitops_hip_tuning.so) additionally hold the measurement variants: launch
 // shapes, ablations, the stamped kernel and the first-generation VALU-only kernel.  The production

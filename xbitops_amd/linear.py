@@ -29,6 +29,10 @@ class QuantLinear(torch.nn.Module):
         self.register_buffer("qzeros", torch.zeros((groups, packing.packed_rows(out_features, bits)), dtype=torch.int32))
         self.bias = torch.nn.Parameter(torch.zeros(out_features, dtype=torch.float16)) if bias else None
         self._plan = None  # ops.GemvPlan for the current buffers (rebuilt when .to() / load_state_dict replaces them)
+        # act-order checkpoints: either the rows were sorted by group at load time and `perm` re-orders the
+        # activation to match (fast: the ordinary kernels), or `g_idx` is kept and the general entry points run
+        self.register_buffer("perm", None)
+        self.register_buffer("g_idx", None)
 
     @classmethod
     def from_float(cls, weight_kn, bits: int, groupsize: int = 128, add_zero_bias: int = 0) -> "QuantLinear":
@@ -42,19 +46,69 @@ class QuantLinear(torch.nn.Module):
         m.qzeros.copy_(torch.from_numpy(qzeros))
         return m
 
+    @classmethod
+    def from_act_order(cls, qweight, scales, qzeros, g_idx, bits: int, groupsize: int, add_zero_bias: int = 0) -> "QuantLinear":
+        """An act-order (GPTQ ``desc_act``) checkpoint: ``g_idx[k]`` is the group of row k (numpy or torch, host).
+        Equal-sized groups are sorted into the contiguous layout once, here (``packing.sort_rows_by_group``);
+        any other ``g_idx`` is kept and served by the general ``*_gidx`` kernels."""
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        qweight, scales, qzeros, g_idx = to_np(qweight), to_np(scales), to_np(qzeros), to_np(g_idx).astype(np.int32)
+        k, n = g_idx.shape[0], qweight.shape[1]
+        m = cls(k, n, bits, groupsize, add_zero_bias)
+        if scales.shape[0] != m.scales.shape[0]:
+            raise ValueError("scales must have ceil(in_features / groupsize) rows")
+        try:
+            qweight, perm = packing.sort_rows_by_group(qweight, g_idx, bits, groupsize)
+            m.perm = torch.from_numpy(perm)
+        except ValueError:
+            m.g_idx = torch.from_numpy(g_idx)
+        m.qweight.copy_(torch.from_numpy(np.ascontiguousarray(qweight).view(np.int32)))
+        m.scales.copy_(torch.from_numpy(np.ascontiguousarray(scales, dtype=np.float16)))
+        m.qzeros.copy_(torch.from_numpy(np.ascontiguousarray(qzeros).view(np.int32)))
+        return m
+
+    @classmethod
+    def from_transposed_w4(cls, qweight_t, scales_t, qzeros_t, groupsize: int, in_features: int, add_zero_bias: int = 0) -> "QuantLinear":
+        """The transposed 4-bit layout of the reference's experimental gemv_NT (gemv_w4a16_nt.cu:64-159)."""
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        qweight, scales, qzeros = packing.from_transposed_w4(to_np(qweight_t), to_np(scales_t), to_np(qzeros_t))
+        m = cls(in_features, qweight.shape[1], 4, groupsize, add_zero_bias)
+        m.qweight.copy_(torch.from_numpy(qweight.view(np.int32)))
+        m.scales.copy_(torch.from_numpy(scales.astype(np.float16)))
+        m.qzeros.copy_(torch.from_numpy(qzeros.view(np.int32)))
+        return m
+
     def dequantize(self) -> torch.Tensor:
-        return ops.dequant(self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
+        """``W[K, N]`` in the ORIGINAL row order (what ``x @ W`` multiplies), whatever the storage order."""
+        if self.g_idx is not None:
+            return ops.dequant_gidx(self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.in_features, self.add_zero_bias)
+        w = ops.dequant(self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
+        if self.perm is not None:
+            out = torch.empty_like(w)
+            out[self.perm] = w  # W_sorted[k'] = W[perm[k']]
+            return out
+        return w
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.in_features).to(torch.float16).contiguous()
+        if self.g_idx is not None:  # general act-order: the group of row k is g_idx[k]
+            if x2.shape[0] <= GEMV_MAX_ROWS:
+                y = ops.gemv_gidx(x2, self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.in_features, self.add_zero_bias)
+            else:
+                y = x2 @ self.dequantize()
+            if self.bias is not None:
+                y = y + self.bias
+            return y.reshape(*lead, self.out_features)
+        if self.perm is not None:  # rows sorted by group at load time: the same sum over k in that order
+            x2 = x2.index_select(1, self.perm)
         if x2.shape[0] <= GEMV_MAX_ROWS:
             plan = self._plan
             if plan is None or not plan.matches(self.qweight, self.scales, self.qzeros):
                 plan = self._plan = ops.GemvPlan(self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
             y = plan(x2)
         else:
-            y = x2 @ self.dequantize()
+            y = x2 @ ops.dequant(self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
         if self.bias is not None:
             y = y + self.bias
         return y.reshape(*lead, self.out_features)

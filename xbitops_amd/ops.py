@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["dequant", "gemv", "gemv_ex", "gemv_multi", "GemvPlan"]
+__all__ = ["dequant", "gemv", "gemv_ex", "gemv_gidx", "dequant_gidx", "gemv_multi", "GemvPlan"]
 
 
 def _check_input(t: torch.Tensor, name: str) -> None:
@@ -184,6 +184,80 @@ def gemv_ex(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, 
                                           bits, groupsize, mat_m, in_features, n, bias, _stream_ptr(idx), opts)
             _lib.check(st, "XbitOps.gemv")
     return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out  # :74-76
+
+
+def _check_gidx(g_idx: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, in_features: int) -> None:
+    _check_input(g_idx, "g_idx")
+    if g_idx.dtype != torch.int32 or g_idx.dim() != 1 or g_idx.numel() != in_features:
+        raise RuntimeError("g_idx must be int32 [in_features]")
+    if g_idx.device != qweight.device:
+        raise RuntimeError("g_idx and weight must be on the same device")
+
+
+def _check_common_gidx(qweight, scales, qzeros, bits: int, in_features: int) -> int:
+    """The operator checks with the group count taken from ``scales`` (no groupsize with act-order)."""
+    groups = scales.size(0) if scales.dim() == 2 else 0
+    if groups < 1:
+        raise RuntimeError("scales must be [groups, N]")
+    # groupsize = in_features makes ceil(in_features / groupsize) == 1 <= groups: the row checks of _check_common hold for any G
+    _check_common(qweight, scales, qzeros, max(16, in_features), bits, in_features)
+    if qzeros.size(0) < groups:
+        raise RuntimeError("qzeros must have one row per group")
+    return groups
+
+
+def gemv_gidx(input_a: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g_idx: torch.Tensor, bits: int,
+              in_features: int, add_zero_bias: int) -> torch.Tensor:
+    """Act-order GEMV (``xbit_gemv_gidx_f16``): the group of row k is ``g_idx[k]``.  Counterpart of the
+    reference's ``vecquant4matmul_g_cuda`` (quant_cuda_kernel.cu:221-336), bits 2..8.  Same shapes and
+    dtypes as :func:`gemv`; ``scales`` / ``qzeros`` have one row per group."""
+    bits, in_features = int(bits), int(in_features)
+    bias = add_zero_bias_check(add_zero_bias)
+    _check_input(input_a, "input_a")
+    groups = _check_common_gidx(qweight, scales, qzeros, bits, in_features)
+    _check_gidx(g_idx, qweight, scales, in_features)
+    if qweight.device != input_a.device:
+        raise RuntimeError("input and weight must be on the same device")
+    if input_a.dtype != torch.float16:
+        raise RuntimeError("input_a must be float16")
+    if input_a.dim() not in (2, 3) or input_a.size(-1) != in_features:
+        raise RuntimeError("input_a must be [B, in_features] or [B, S, in_features], got %s" % (tuple(input_a.shape),))
+    lib = _lib.load()
+    n = qweight.size(1)
+    lead = tuple(input_a.shape[:-1])
+    mat_m = 1
+    for d in lead:
+        mat_m *= d
+    ori_dtype = scales.dtype
+    f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales
+    idx = qweight.device.index
+    with _on_device(idx):
+        out = torch.empty(lead + (n,), dtype=torch.float16, device=qweight.device)
+        if mat_m > 0:
+            st = lib.xbit_gemv_gidx_f16(out.data_ptr(), input_a.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(),
+                                        g_idx.data_ptr(), bits, groups, mat_m, in_features, n, bias, _stream_ptr(idx))
+            _lib.check(st, "XbitOps.gemv_gidx")
+    return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out
+
+
+def dequant_gidx(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g_idx: torch.Tensor, bits: int, in_features: int,
+                 add_zero_bias: int) -> torch.Tensor:
+    """Act-order dequant (``xbit_dequant_gidx_f16``): ``W[in_features, N]`` with the group of row k = ``g_idx[k]``."""
+    bits, in_features = int(bits), int(in_features)
+    bias = add_zero_bias_check(add_zero_bias)
+    groups = _check_common_gidx(qweight, scales, qzeros, bits, in_features)
+    _check_gidx(g_idx, qweight, scales, in_features)
+    lib = _lib.load()
+    ori_dtype = scales.dtype
+    f16_scale = scales.to(torch.float16) if ori_dtype == torch.bfloat16 else scales
+    n = qweight.size(1)
+    idx = qweight.device.index
+    with _on_device(idx):
+        out = torch.empty((in_features, n), dtype=torch.float16, device=qweight.device)
+        st = lib.xbit_dequant_gidx_f16(out.data_ptr(), qweight.data_ptr(), f16_scale.data_ptr(), qzeros.data_ptr(), g_idx.data_ptr(), bits,
+                                       groups, in_features, n, bias, _stream_ptr(idx))
+    _lib.check(st, "XbitOps.dequant_gidx")
+    return out.to(torch.bfloat16) if ori_dtype == torch.bfloat16 else out
 
 
 def gemv_multi(input_a: torch.Tensor, weights, groupsize: int, bits: int, in_features: int, add_zero_bias: int):

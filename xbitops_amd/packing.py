@@ -18,7 +18,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["packed_rows", "pack_stream", "pack_qweight", "pack_qzeros", "quantize_rtn"]
+__all__ = ["packed_rows", "pack_stream", "unpack_stream", "pack_qweight", "pack_qzeros", "quantize_rtn", "sort_rows_by_group",
+           "from_transposed_w4"]
 
 
 def packed_rows(count: int, bits: int) -> int:
@@ -91,3 +92,50 @@ def quantize_rtn(w: np.ndarray, bits: int, groupsize: int, add_zero_bias: int = 
         scales[g] = s
         zeros[g] = z - add_zero_bias
     return pack_qweight(q, bits), scales, pack_qzeros(zeros.astype(np.uint8), bits)
+
+
+def unpack_stream(words: np.ndarray, bits: int, length: int) -> np.ndarray:
+    """Inverse of :func:`pack_stream`: ``uint32[ceil(L*b/32), C]`` -> ``uint8[L, C]``."""
+    w = np.ascontiguousarray(words).view(np.uint32).astype(np.uint64)
+    rows, cols = w.shape
+    w = np.concatenate([w, np.zeros((1, cols), np.uint64)], axis=0)  # spare word for the last field's (empty) spill
+    i = np.arange(length, dtype=np.int64) * bits
+    wi, sh = i >> 5, (i & 31).astype(np.uint64)
+    pair = w[wi] | (w[wi + 1] << np.uint64(32))
+    return ((pair >> sh[:, None]) & np.uint64((1 << bits) - 1)).astype(np.uint8)
+
+
+def sort_rows_by_group(qweight: np.ndarray, g_idx: np.ndarray, bits: int, groupsize: int):
+    """Act-order checkpoint -> the contiguous-group layout the ordinary kernels take.
+
+    ``g_idx[k]`` is the group of row ``k`` (GPTQ ``desc_act``).  When every group holds exactly
+    ``groupsize`` rows (the last one may hold fewer), sorting the rows by group makes
+    ``g = k' // groupsize`` true again: returns ``(qweight_sorted, perm)`` with
+    ``W_sorted[k'] = W[perm[k']]``, so ``x @ W == x[..., perm] @ W_sorted`` (a sum over k in another
+    order).  Raises ``ValueError`` for any other ``g_idx`` — use the general ``*_gidx`` entry points then.
+    """
+    gi = np.ascontiguousarray(g_idx).astype(np.int64)
+    k = gi.shape[0]
+    groups = (k + groupsize - 1) // groupsize
+    if gi.min() < 0 or gi.max() >= groups:
+        raise ValueError("g_idx values must lie in [0, %d)" % groups)
+    counts = np.bincount(gi, minlength=groups)
+    want = np.full(groups, groupsize, np.int64)
+    want[-1] = k - (groups - 1) * groupsize
+    if not np.array_equal(counts, want):
+        raise ValueError("groups are not all of size %d: the rows cannot be sorted into the contiguous-group layout" % groupsize)
+    perm = np.argsort(gi, kind="stable")
+    q = unpack_stream(np.ascontiguousarray(qweight).view(np.uint32), bits, k)
+    return pack_qweight(q[perm], bits), perm.astype(np.int64)
+
+
+def from_transposed_w4(qweight_t: np.ndarray, scales_t: np.ndarray, qzeros_t: np.ndarray):
+    """The transposed 4-bit layout of the reference's experimental ``gemv_NT``
+    (/root/reference/src/cu/gemv_w4a16_nt.cu:64-159: ``qweight_t [N, K/8]``, ``scales_t [N, G]``,
+    ``qzeros_t [N/8, G]``) -> the registered ops' layout.  With 8 nibbles per word on both axes the
+    conversion is three plain transposes: word ``(n, k/8)`` holds k..k+7 of column n exactly as word
+    ``(k/8, n)`` of ``qweight`` does (``:104`` vs gemv_w4a16_pt.cu:73), and word ``(n/8, g)`` holds the
+    zero-points of columns n..n+7 exactly as word ``(g, n/8)`` of ``qzeros`` (``:87-89`` vs
+    gemv_w4a16_pt.cu:53-58)."""
+    return (np.ascontiguousarray(np.asarray(qweight_t).T), np.ascontiguousarray(np.asarray(scales_t).T),
+            np.ascontiguousarray(np.asarray(qzeros_t).T))
