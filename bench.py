@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--shape", default="", help="K,N,bits,group,M: another single-GPU workload (profiling configs 3 and 5)")
+    ap.add_argument("--op", choices=("gemv", "dequant"), default="gemv", help="dequant: time xbit_dequant_f16 on the --shape instead (write-bound; SURVEY 8f rank 1)")
     ap.add_argument("--graph", action="store_true", help="one GPU: time a hipGraph replay of the K launches instead of queued eager launches")
     ap.add_argument("--no-graph", action="store_true", help="accepted for compatibility (eager launches are the default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
@@ -245,6 +246,11 @@ def main(argv=None):
         del base
     n_local = qw_h.shape[1]
     nbytes = synth.algorithmic_bytes(k_in, n_local, bits, group, batch)  # per rank and step
+    if args.op == "dequant":
+        if world > 1 or not args.shape:
+            raise SystemExit("--op dequant is a single-GPU --shape workload")
+        nbytes = synth.dequant_bytes(k_in, n_local, bits, group)
+        workload = "dequant W%d in=%d out=%d group=%d (--op dequant)" % (bits, k_in, n_full, group)
     copies = (COLD_BYTES + nbytes - 1) // nbytes + 1  # >= 512 MB of distinct weights per GPU
     act = torch.from_numpy(act_h).to(dev)
     qw0, sc0, qz0 = torch.from_numpy(qw_h).to(dev), torch.from_numpy(sc_h).to(dev), torch.from_numpy(qz_h).to(dev)
@@ -255,7 +261,9 @@ def main(argv=None):
         scs.append(sc0.clone())
         qzs.append((qz0 ^ (0x11111111 * (c % 13))).contiguous())
     n_out_bufs = 4
-    outs = torch.empty((n_out_bufs, batch, n_local), dtype=torch.float16, device=dev)
+    if args.op == "dequant":  # rotate the outputs too: [K, N] fp16 each, > 512 MB in total so that no write stays cached
+        n_out_bufs = max(2, min(copies, (COLD_BYTES + 2 * k_in * n_local - 1) // (2 * k_in * n_local) + 1))
+    outs = torch.empty((n_out_bufs, k_in if args.op == "dequant" else batch, n_local), dtype=torch.float16, device=dev)
     gathered = torch.empty((n_out_bufs, world, batch, n_local), dtype=torch.float16, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
@@ -267,7 +275,9 @@ def main(argv=None):
 
     def kernel_step(i: int, stream_ptr: int) -> None:
         qw, sc, qz = ptrs[i % copies]
-        if gemv_opts is None:
+        if args.op == "dequant":
+            st = lib.xbit_dequant_f16(out_ptrs[i % n_out_bufs], qw, sc, qz, bits, group, k_in, n_local, 1, stream_ptr)
+        elif gemv_opts is None:
             st = gemv(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, bits, group, batch, k_in, n_local, 1, stream_ptr)
         else:
             st = lib.xbit_gemv_f16_ex(out_ptrs[i % n_out_bufs], a_ptr, qw, sc, qz, bits, group, batch, k_in, n_local, 1, stream_ptr, gemv_opts)
@@ -370,7 +380,8 @@ def main(argv=None):
         off = offline_profile(workload if world == 1 else "", sha) if cfg_name != "shape" else None
         traffic = off["traffic_bytes_per_launch"] if off and off.get("matches_this_build") else None
         rec = {
-            "metric": "A16W%d GEMV GB/s at %dx%d g%d batch=%d (algorithmic bytes / time; cold HBM)" % (bits, k_in, n_full, group, batch),
+            "metric": ("dequant W%d GB/s at %dx%d g%d (bytes read + written / time; cold HBM)" % (bits, k_in, n_full, group)) if args.op == "dequant" else
+                      "A16W%d GEMV GB/s at %dx%d g%d batch=%d (algorithmic bytes / time; cold HBM)" % (bits, k_in, n_full, group, batch),
             "value": round(value, 2),
             "unit": "GB/s",
             "n_gpus": world,

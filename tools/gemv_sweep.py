@@ -88,10 +88,19 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--shape", default="4096,11008,4,128,1", help="K,N,bits,group,M for the variant loop")
     ap.add_argument("--splits", default="0", help="split-K factors to try per variant (0 = automatic, 1 = never split)")
+    ap.add_argument("--dequant-only", action="store_true", help="only the dequant cases (XBIT_DEQUANT_VARIANT selects a measurement variant: tuning library)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     print("device:", torch.cuda.get_device_name(0), flush=True)
+    if args.dequant_only:
+        dl = _lib.load_tuning() if os.environ.get("XBIT_DEQUANT_VARIANT") else lib
+        tag = "variant " + os.environ.get("XBIT_DEQUANT_VARIANT", "0")
+        for bits in (2, 4, 8):
+            show("dequant w%d 4096x4096 %s cold" % (bits, tag), *dequant_case(dl, dev, 4096, 4096, bits, 128))
+        for bits in (3, 4):
+            show("dequant w%d 4096x11008 %s cold" % (bits, tag), *dequant_case(dl, dev, 4096, 11008, bits, 128))
+        return
     sk, sn, sb, sg, sm = (int(x) for x in args.shape.split(","))
     for v in [int(x) for x in args.variants.split(",") if x != ""]:
         vlib = _lib.load_tuning() if v > 0 else lib  # measurement variants live in the tuning build only

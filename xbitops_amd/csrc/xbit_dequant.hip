@@ -11,6 +11,8 @@
 // contiguous bytes of every output row.  The arithmetic is the reference's, bit for bit:
 //   zs = hmul(half(z + bias), s);  W = hfma(half(q), s, -zs)      (:60,75 and :285,305)
 // packed over column pairs (c, c+1) so that each result is already the dword to store.
+#include <stdlib.h>
+
 #include "xbit_device.h"
 #include "xbit_host.h"
 
@@ -22,11 +24,17 @@ constexpr int kDqLanesN = 64;  // lanes along N (x 8 columns = 512 columns: a wa
 constexpr int kDqLanesK = 4;   // k-blocks per workgroup (one per wave)
 constexpr int kDqThreads = kDqLanesN * kDqLanesK;
 
-template <int BITS, bool GROUP_PER_BLOCK>
+// Packed weights are read with PLAIN loads, W is written with nontemporal stores: measured on MI355X
+// (profiles/r02/sweep_dequant_variants.txt) nontemporal weight loads cost 7-8 % (4096x11008 w4: 20.5 us
+// against 19.05), plain stores cost 2-15 %.
+// VAR (measurement builds, XBIT_DEQUANT_VARIANT): 0 = production; 1 = plain (not nontemporal) stores;
+// 2 = the 4 waves of a workgroup side by side along N (one k-block, 2048 columns: 4 KB per output row);
+// 3 = nontemporal packed-weight loads (the round-1 kernel)
+template <int BITS, bool GROUP_PER_BLOCK, int VAR = 0>
 __global__ void __launch_bounds__(kDqThreads) dequant_tile_kernel(const DequantParams p) {
   const int nl = threadIdx.x % kDqLanesN, kl = threadIdx.x / kDqLanesN;
-  const uint32_t col = (blockIdx.x * kDqLanesN + nl) * 8u;
-  const uint32_t kb = blockIdx.y * kDqLanesK + kl;
+  const uint32_t col = VAR == 2 ? ((blockIdx.x * kDqLanesK + kl) * kDqLanesN + nl) * 8u : (blockIdx.x * kDqLanesN + nl) * 8u;
+  const uint32_t kb = VAR == 2 ? blockIdx.y : blockIdx.y * kDqLanesK + kl;
   if (col >= p.n || kb >= p.kblocks) return;  // n % 8 == 0 on this path
   const uint32_t k0 = kb * 32u;
 
@@ -37,8 +45,8 @@ __global__ void __launch_bounds__(kDqThreads) dequant_tile_kernel(const DequantP
     const uint32_t row = kb * BITS + i;
     if (row < p.kw) {
       const uint32_t* src = p.qweight + (size_t)row * p.n + col;
-      wlo[i] = ld16_nt(src);
-      whi[i] = ld16_nt(src + 4);
+      wlo[i] = VAR == 3 ? ld16_nt(src) : ld16(src);
+      whi[i] = VAR == 3 ? ld16_nt(src + 4) : ld16(src + 4);
     } else {
       wlo[i] = whi[i] = make_uint4(0, 0, 0, 0);
     }
@@ -91,7 +99,10 @@ __global__ void __launch_bounds__(kDqThreads) dequant_tile_kernel(const DequantP
       const uint32_t Q = field<BITS>(wcol[2 * c2], kk) | (field<BITS>(wcol[2 * c2 + 1], kk) << 16) | kMagic1024x2;
       o[c2] = as_u32(dequant_pair(Q, s2[c2], nzs2[c2]));
     }
-    if (row_ok) st16_nt(orow + (size_t)kk * p.n, make_uint4(o[0], o[1], o[2], o[3]));
+    if (row_ok) {
+      if constexpr (VAR == 1) *reinterpret_cast<u32x4_t*>(orow + (size_t)kk * p.n) = u32x4_t{o[0], o[1], o[2], o[3]};
+      else st16_nt(orow + (size_t)kk * p.n, make_uint4(o[0], o[1], o[2], o[3]));
+    }
   }
 }
 
@@ -111,6 +122,15 @@ __global__ void __launch_bounds__(256) dequant_generic_kernel(const DequantParam
 template <int BITS>
 int launch_bits(const DequantParams& p, hipStream_t stream) {
   dim3 grid((p.n / 8 + kDqLanesN - 1) / kDqLanesN, (p.kblocks + kDqLanesK - 1) / kDqLanesK), block(kDqThreads);
+#if XBIT_TUNING
+  static const int var = getenv("XBIT_DEQUANT_VARIANT") ? atoi(getenv("XBIT_DEQUANT_VARIANT")) : 0;
+  if (p.groupsize % 32u == 0 && var == 1) return launch(dequant_tile_kernel<BITS, true, 1>, grid, block, stream, p);
+  if (p.groupsize % 32u == 0 && var == 3) return launch(dequant_tile_kernel<BITS, true, 3>, grid, block, stream, p);
+  if (p.groupsize % 32u == 0 && var == 2) {
+    dim3 grid2((p.n / 8 + kDqLanesN * kDqLanesK - 1) / (kDqLanesN * kDqLanesK), p.kblocks);
+    return launch(dequant_tile_kernel<BITS, true, 2>, grid2, block, stream, p);
+  }
+#endif
   if (p.groupsize % 32u == 0) return launch(dequant_tile_kernel<BITS, true>, grid, block, stream, p);
   return launch(dequant_tile_kernel<BITS, false>, grid, block, stream, p);
 }

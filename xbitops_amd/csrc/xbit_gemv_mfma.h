@@ -55,18 +55,26 @@ struct LoadSchedule {
   // loads step s consumes: all rows of earlier blocks plus the rows holding the octet's pairs
   static constexpr int need(int s) { return (s / 4) * BITS + Unpack<BITS>::rows_for_octet(s % 4); }
   // loads issued once step s's prefetch is out (LA == 0: everything up front)
+  // LA >= 100 (measurement builds): a ramp - lookahead la0 = (LA-100)/10 before the first step, one more per
+  // step up to lamax = (LA-100)%10: every wave starts with a short burst (the CU serves waves' bursts one
+  // after the other), the window then widens while the wave computes
+  static constexpr int la_at(int s) {
+    if (LA < 100) return LA;
+    const int la0 = (LA - 100) / 10, lamax = (LA - 100) % 10;
+    return la0 + s < lamax ? la0 + s : lamax;
+  }
   static constexpr int issued_before(int s) {
     if (LA == 0) return kTotal;
-    return need(s) + LA < kTotal ? need(s) + LA : kTotal;
+    return need(s) + la_at(s) < kTotal ? need(s) + la_at(s) : kTotal;
   }
 };
 
 // CPL adjacent packed words of one row (8 / 12 / 16 bytes per lane)
-template <int CPL, bool NT>
+template <int CPL, bool NT, int AUXX = 0>
 struct RowLoad {
   uint32_t v[CPL];
   __device__ __forceinline__ void load(rsrc_t r, uint32_t voff, uint32_t soff) {
-    constexpr int aux = NT ? 2 : 0;  // nt: read-once stream
+    constexpr int aux = (NT ? 2 : 0) | AUXX;  // nt: read-once stream; AUXX (measurement builds): 1 = sc0, 16 = sc1
     if constexpr (CPL == 2) {
       const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux);
       v[0] = t.x; v[1] = t.y;
@@ -117,6 +125,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   static_assert(!MULTI || (GUARD && !SPLIT && ABLATE == 0), "fused launches use the guarded, unsplit build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
+  constexpr bool WFIRST = (ABLATE & 1024) != 0;  // measurement: first weight rows issued ahead of the activation slice
   constexpr int LK = 64 / NL;                // k-slots per wave
   constexpr int RS = NL < 16 ? 16 / NL : 1;  // NL = 8: k-slots sharing one MFMA k-octet (in different column slots)
   constexpr int CS = NL > 16 ? NL / 16 : 1;  // NL = 32: column sets sharing the 16 column slots (in different k-octets)
@@ -210,6 +219,31 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     const uint32_t bt = wb + kl;       // this lane's batch
     const bool active = GUARD ? (col_ok && bt < b_end) : true;
 
+    // (3) all packed-weight loads of this lane's batch: one 32-bit lane offset, the row step rides in
+    //     the scalar offset.  Rows past the end of qweight read 0 (their activations are 0 as well).
+    RowLoad<CPL, NT, ((ABLATE & 256) ? 16 : 0) | ((ABLATE & 512) ? 1 : 0)> w[UB][BITS];
+    uint32_t lane_off = (bt * (uint32_t)(UB * BITS)) * row_bytes + col * 4u;
+    if (GUARD && !active) lane_off = kOob;
+    using LS = LoadSchedule<BITS, UB, LA>;
+    auto issue_range = [&](auto from_c, auto to_c) {
+      constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
+      static_for<(to > from ? to - from : 0)>([&](auto d) {
+        constexpr int idx = from + decltype(d)::value, j = idx / BITS, i = idx % BITS;
+        if constexpr (ABLATE & 1) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) w[j][i].v[c] = lane_off * (uint32_t)(2 * c + 3) + (uint32_t)idx * 0x9E3779B1u;
+        } else {
+          w[j][i].load(r_w, lane_off, (uint32_t)idx * row_bytes);
+        }
+      });
+    };
+    if constexpr (WFIRST) {
+      // weights first: with 8-16 rows per pass the activation slice alone is 8-16 loads per lane, and
+      // issued in front of the weights it holds back the start of the HBM stream by about a microsecond
+      issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, LS::issued_before(0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
     // (1) activation slice of this wave (oldest loads in the vmcnt queue).  Rows >= M fall off the
     //     end of the buffer and read 0; k >= K must be forced out of range (it would alias row m+1).
     u32x4_t hraw[ROUNDS][CPT];
@@ -271,27 +305,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       }
     }
 
-    // (3) all packed-weight loads of this lane's batch: one 32-bit lane offset, the row step rides in
-    //     the scalar offset.  Rows past the end of qweight read 0 (their activations are 0 as well).
-    RowLoad<CPL, NT> w[UB][BITS];
-    uint32_t lane_off = (bt * (uint32_t)(UB * BITS)) * row_bytes + col * 4u;
-    if (GUARD && !active) lane_off = kOob;
-    using LS = LoadSchedule<BITS, UB, LA>;
-    auto issue_range = [&](auto from_c, auto to_c) {
-      constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
-      static_for<(to > from ? to - from : 0)>([&](auto d) {
-        constexpr int idx = from + decltype(d)::value, j = idx / BITS, i = idx % BITS;
-        if constexpr (ABLATE & 1) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) w[j][i].v[c] = lane_off * (uint32_t)(2 * c + 3) + (uint32_t)idx * 0x9E3779B1u;
-        } else {
-          w[j][i].load(r_w, lane_off, (uint32_t)idx * row_bytes);
-        }
-      });
-    };
-    issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, LS::issued_before(0)>{});
-    // Pin the issue order act -> scale/zero -> weights: each wait below then leaves every younger
-    // load in flight (vmcnt retires in order).
+    if constexpr (!WFIRST) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, LS::issued_before(0)>{});
+    // Pin the issue order act -> scale/zero -> weights (WFIRST: first weights -> act -> scale/zero): each
+    // wait below then leaves every younger load in flight (vmcnt retires in order).
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ABLATE & 8) {
       if (b0 == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();  // all loads of the first sweep issued
@@ -638,6 +654,16 @@ int launch_la(GemvParams p, hipStream_t stream) {
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
 }
 
+// measurement-only launch of the 16-row pass (NL = 16, 8 waves) with ABLATE bits
+template <int BITS, int UB, int CPL, int ABLATE>
+int launch_rows16_ablate(GemvParams p, hipStream_t stream) {
+  constexpr int CN = 16 * CPL;
+  p.tiles = (p.n + CN - 1) / CN;
+  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
+  dim3 grid(p.tiles, (p.m + 15) / 16), block(64 * sweep_waves(p.batches, 4, 8));
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, 8, 16, false, true, ABLATE, lookahead_for<BITS>()>, grid, block, stream, p);
+}
+
 // rows per pass: 1, 4, 8 or 16 (fewer staged rows = less LDS traffic); NL = 8 / 32 tiles take <= 8 rows.
 // Workgroup size: up to 16 waves when there is at most one workgroup per CU (<= 240 tiles), up to 8
 // otherwise (several 8-wave workgroups per CU sweeping K measured better: 8192x28672 26.2 -> 25.3 us,
@@ -747,6 +773,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
 #endif
   if (p.groupsize % (32u * UBMAX) == 0) {
 #if XBIT_TUNING
+    if (variant == 180 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 1024>(p, stream);  // 16-row pass, weights first
+    if (variant == 181 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 0>(p, stream);     // same launch, production order
+    if (variant == 182 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32>(p, stream);    // no activation staging at all (wrong results): the floor
     if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
         case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
@@ -788,6 +817,22 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 64: return launch_la<BITS, 4, 3, 16, 8, 16, kLookahead>(p, stream);  // VALU accumulate (v_dot2) instead of MFMA
           // round-2 experiments: loads-only builds at other lookaheads, full builds at LA 5 / 12, 16 waves at deeper LA
           case 131: return launch_la<BITS, 4, 3, 16, 8, 2, 0>(p, stream);
+          case 183: return launch_la<BITS, 4, 3, 16, 8, 1024, 4>(p, stream);     // M = 1, first weight rows ahead of the small operands
+          case 170: return launch_m1<BITS, 4, 3, 16, 8, false, 138>(p, stream);   // lookahead ramp 3 -> 8
+          case 171: return launch_m1<BITS, 4, 3, 16, 8, false, 148>(p, stream);   // 4 -> 8
+          case 172: return launch_m1<BITS, 4, 3, 16, 8, false, 126>(p, stream);   // 2 -> 6
+          case 173: return launch_m1<BITS, 4, 3, 16, 8, false, 146>(p, stream);   // 4 -> 6
+          case 174: return launch_m1<BITS, 4, 3, 16, 8, false, 139>(p, stream);   // 3 -> 9
+          case 175: return launch_m1<BITS, 4, 3, 16, 8, false, 128>(p, stream);   // 2 -> 8
+          case 176: return launch_m1<BITS, 4, 4, 16, 8, false, 138>(p, stream);   // 64-column tiles, 3 -> 8
+          case 177: return launch_m1<BITS, 4, 4, 16, 8, false, 126>(p, stream);   // 64-column tiles, 2 -> 6
+          case 160: return launch_la<BITS, 4, 3, 16, 8, 256, 4>(p, stream);         // weight loads sc1 (L1 bypass?)
+          case 161: return launch_la<BITS, 4, 3, 16, 8, 256 | 512, 4>(p, stream);   // sc0 sc1
+          case 162: return launch_la<BITS, 4, 3, 16, 8, 256, 8>(p, stream);         // sc1, lookahead 8
+          case 163: return launch_la<BITS, 4, 3, 16, 8, 256 | 512, 8>(p, stream);   // sc0 sc1, lookahead 8
+          case 164: return launch_m1<BITS, 4, 3, 16, 8, true, 8>(p, stream);        // nt, lookahead 8
+          case 165: return launch_la<BITS, 4, 3, 16, 8, 256, 6>(p, stream);         // sc1, lookahead 6
+          case 166: return launch_la<BITS, 4, 3, 16, 8, 512, 6>(p, stream);         // sc0, lookahead 6
           case 150: return launch_la<BITS, 4, 3, 16, 8, 2 | 32, 4>(p, stream);              // loads only, no activation staging
           case 151: return launch_la<BITS, 4, 3, 16, 8, 2 | 64, 4>(p, stream);              // loads only, no scale / zero loads
           case 152: return launch_la<BITS, 4, 3, 16, 8, 2 | 128, 4>(p, stream);             // loads only, no LDS reduction
