@@ -43,10 +43,23 @@ def _check_round2(rec):
 
 
 def test_committed_bench_line_follows_the_contract():
-    logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench.json.log")))
+    """The bench lines committed with the round's profiles (the metric config and the cfg4 mode)."""
+    logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench", "cfg2_*", "bench.json.log")))
     assert logs, "no committed bench line"
     line = [ln for ln in open(logs[-1]).read().splitlines() if ln.startswith("{")][-1]
-    _check(json.loads(line), need_cpu_baseline=False)  # the profiled run uses --no-cpu
+    rec = json.loads(line)
+    _check(rec, need_cpu_baseline=False)  # the profiled run uses --no-cpu
+    _check_round2(rec)
+    assert rec["config"]["algorithmic_bytes_per_step"] == 23455232 and rec["value"] >= 0.9 * rec["roofline"]["achieved"]
+    cfg4 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench", "cfg4_w4_8192x28672*", "bench.json.log")))
+    rec4 = json.loads([ln for ln in open(cfg4[-1]).read().splitlines() if ln.startswith("{")][-1])
+    _check(rec4, need_cpu_baseline=False, scaling="strong")
+    assert rec4["config"]["algorithmic_bytes_per_step"] == 122101760
+    # every profiled config carries its PMC traffic, taken from the library that produced the bench line
+    for d in glob.glob(os.path.join(ROOT, "profiles", "r02", "bench", "*")):
+        t = json.load(open(os.path.join(d, "pmc_traffic.json")))
+        b = json.loads([ln for ln in open(os.path.join(d, "bench.json.log")).read().splitlines() if ln.startswith("{")][-1])
+        assert t["lib_sha256"] == b["lib_sha256"] and 0.98 <= t["traffic_over_algorithmic"] <= 1.10, d
 
 
 @pytest.mark.gpu
