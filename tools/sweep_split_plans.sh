@@ -1,0 +1,4 @@
+for shape in 8192,3584 11008,4096 14336,4096 28672,4096 28672,2048 16384,1024 8192,2048 8192,4096 13824,5120 8192,1024; do
+  python tools/gemv_sweep.py --quick --shape $shape,4,128,1 --variants=-1 --splits 0,1
+  python tools/gemv_sweep.py --quick --shape $shape,4,128,1 --variants=202,205 --splits 2,3,4,6,8
+done

@@ -29,12 +29,12 @@ constexpr int kDqThreads = kDqLanesN * kDqLanesK;
 // against 19.05), plain stores cost 2-15 %.
 // VAR (measurement builds, XBIT_DEQUANT_VARIANT): 0 = production; 1 = plain (not nontemporal) stores;
 // 2 = the 4 waves of a workgroup side by side along N (one k-block, 2048 columns: 4 KB per output row);
-// 3 = nontemporal packed-weight loads (the round-1 kernel)
-template <int BITS, bool GROUP_PER_BLOCK, int VAR = 0>
-__global__ void __launch_bounds__(kDqThreads) dequant_tile_kernel(const DequantParams p) {
+// 3 = nontemporal packed-weight loads (the round-1 kernel); 5 / 6 / 7 = 8 / 2 / 1 waves per workgroup
+template <int BITS, bool GROUP_PER_BLOCK, int VAR = 0, int WAVES = kDqLanesK>
+__global__ void __launch_bounds__(kDqLanesN * WAVES) dequant_tile_kernel(const DequantParams p) {
   const int nl = threadIdx.x % kDqLanesN, kl = threadIdx.x / kDqLanesN;
-  const uint32_t col = VAR == 2 ? ((blockIdx.x * kDqLanesK + kl) * kDqLanesN + nl) * 8u : (blockIdx.x * kDqLanesN + nl) * 8u;
-  const uint32_t kb = VAR == 2 ? blockIdx.y : blockIdx.y * kDqLanesK + kl;
+  const uint32_t col = VAR == 2 ? ((blockIdx.x * WAVES + kl) * kDqLanesN + nl) * 8u : (blockIdx.x * kDqLanesN + nl) * 8u;
+  const uint32_t kb = VAR == 2 ? blockIdx.y : blockIdx.y * WAVES + kl;
   if (col >= p.n || kb >= p.kblocks) return;  // n % 8 == 0 on this path
   const uint32_t k0 = kb * 32u;
 
@@ -126,6 +126,13 @@ int launch_bits(const DequantParams& p, hipStream_t stream) {
   static const int var = getenv("XBIT_DEQUANT_VARIANT") ? atoi(getenv("XBIT_DEQUANT_VARIANT")) : 0;
   if (p.groupsize % 32u == 0 && var == 1) return launch(dequant_tile_kernel<BITS, true, 1>, grid, block, stream, p);
   if (p.groupsize % 32u == 0 && var == 3) return launch(dequant_tile_kernel<BITS, true, 3>, grid, block, stream, p);
+  if (p.groupsize % 32u == 0 && (var == 5 || var == 6 || var == 7)) {  // 8 / 2 / 1 waves (k-blocks) per workgroup
+    const uint32_t wv = var == 5 ? 8u : var == 6 ? 2u : 1u;
+    dim3 gridw((p.n / 8 + kDqLanesN - 1) / kDqLanesN, (p.kblocks + wv - 1) / wv), blockw(kDqLanesN * wv);
+    if (var == 5) return launch(dequant_tile_kernel<BITS, true, 0, 8>, gridw, blockw, stream, p);
+    if (var == 6) return launch(dequant_tile_kernel<BITS, true, 0, 2>, gridw, blockw, stream, p);
+    return launch(dequant_tile_kernel<BITS, true, 0, 1>, gridw, blockw, stream, p);
+  }
   if (p.groupsize % 32u == 0 && var == 2) {
     dim3 grid2((p.n / 8 + kDqLanesN * kDqLanesK - 1) / (kDqLanesN * kDqLanesK), p.kblocks);
     return launch(dequant_tile_kernel<BITS, true, 2>, grid2, block, stream, p);

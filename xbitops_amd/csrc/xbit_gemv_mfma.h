@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   //            slots but sit in octets of different parity; row block rb must see ZERO in the octets of
   //            the other set, so D[rb*8 + m][slot] sums column set rb only.
   const int arow = (CS > 1 ? (nl & 7) : nl) % MT;  // activation row this lane feeds to its row block
-  int a_off = (arow * LK + kl) * KLS;
+  int a_off = (kl * MT + arow) * KLS;  // slot order [k-slot][row]: the 16 lanes one ds_read_b128 pass serves then hit 16 different slots (no bank conflict at 8-16 rows)
   if constexpr (CS > 1) {
     if ((nl >> 4) != ((nl >> 3) & 1)) a_off = MT * LK * KLS;  // the zero slot
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
         h[4 * q + 2] = hraw[r][q].z;
         h[4 * q + 3] = hraw[r][q].w;
       }
-      uint32_t* dst = my_act + (mi * LK + blk / UB) * KLS + (blk % UB) * 16 + cib * (CHK / 2);
+      uint32_t* dst = my_act + ((blk / UB) * MT + mi) * KLS + (blk % UB) * 16 + cib * (CHK / 2);
 #pragma unroll
       for (int q = 0; q < CPT; ++q) {
         uint32_t o[4];
@@ -776,6 +776,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     if (variant == 180 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 1024>(p, stream);  // 16-row pass, weights first
     if (variant == 181 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 0>(p, stream);     // same launch, production order
     if (variant == 182 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32>(p, stream);    // no activation staging at all (wrong results): the floor
+    if (variant == 184 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32 | 128>(p, stream);      // ... and no LDS reduction
+    if (variant == 185 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2 | 32 | 128>(p, stream);  // ... and no arithmetic: loads only
+    if (variant == 186 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 128>(p, stream);           // full kernel minus the LDS reduction
     if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
         case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
@@ -818,6 +821,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           // round-2 experiments: loads-only builds at other lookaheads, full builds at LA 5 / 12, 16 waves at deeper LA
           case 131: return launch_la<BITS, 4, 3, 16, 8, 2, 0>(p, stream);
           case 183: return launch_la<BITS, 4, 3, 16, 8, 1024, 4>(p, stream);     // M = 1, first weight rows ahead of the small operands
+          case 190: return launch_m1<BITS, 2, 4, 8, 8, false>(p, stream);   // 32-column tiles as 8 lanes x 16 B x 8 k-slots (1 KB per instruction), 2 k-blocks per lane
+          case 191: return launch_m1<BITS, 1, 4, 8, 8, false>(p, stream);   // ... 1 k-block per lane
+          case 192: return launch_m1<BITS, 2, 4, 8, 16, false>(p, stream);  // ... 16 waves
           case 170: return launch_m1<BITS, 4, 3, 16, 8, false, 138>(p, stream);   // lookahead ramp 3 -> 8
           case 171: return launch_m1<BITS, 4, 3, 16, 8, false, 148>(p, stream);   // 4 -> 8
           case 172: return launch_m1<BITS, 4, 3, 16, 8, false, 126>(p, stream);   // 2 -> 6
@@ -861,6 +867,12 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
     {
       SplitPlan plan = plan_split(p, UBMAX, opts.split);
+      if (variant == 206 && plan.splits >= 2) {  // measurement: 32-column tiles read as 8 lanes x 16 B (NL = 8), split as planned
+        const uint32_t tiles = (p.n + 31u) / 32u;
+        const size_t slots = (size_t)tiles * 32u;
+        GemvWorkspace ws;
+        if (p.m == 1 && gemv_workspace(stream, slots, opts, &ws)) return launch_split_rows<BITS, 2, 4, 8, 8>(p, stream, plan.splits, ws);
+      }
       if ((variant == 202 || variant == 205) && plan.splits >= 2) {  // sweep hook (tuning builds): force the tile width
         plan.cpl = variant == 202 ? 2 : 4;
       } else if (variant > 0) {
