@@ -171,16 +171,20 @@ def offline_profile(workload_key: str, this_lib_sha: str):
     cannot be read in-process).  `matches_this_build` says whether they were taken from the library
     that is running now; only then do they appear in `roofline`."""
     best = None
-    prof = os.path.join(ROOT, "profiles")
-    for rnd in sorted(d for d in (os.listdir(prof) if os.path.isdir(prof) else []) if d.startswith("r")):
-        path = os.path.join(prof, rnd, "pmc_traffic.json")
+    for root, _dirs, files in sorted(os.walk(os.path.join(ROOT, "profiles"))):
+        if "pmc_traffic.json" not in files:
+            continue
+        path = os.path.join(root, "pmc_traffic.json")
         try:
             with open(path) as f:
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
-        if rec.get("workload") == workload_key:
-            best = dict(rec, source=os.path.relpath(path, ROOT), matches_this_build=rec.get("lib_sha256") == this_lib_sha)
+        if rec.get("workload") != workload_key:
+            continue
+        cand = dict(rec, source=os.path.relpath(path, ROOT), matches_this_build=rec.get("lib_sha256") == this_lib_sha)
+        if best is None or cand["matches_this_build"] or not best["matches_this_build"]:
+            best = cand  # later rounds win; a record of this very build wins over everything
     return best
 
 
