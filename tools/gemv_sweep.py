@@ -41,6 +41,8 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, spli
     base = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
     act = torch.from_numpy(base.act).to(dev)
     qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
+    if 210 <= variant <= 239:  # tile-contiguous address probes read a stream up to 1/8 longer than qweight (meta rows): give them real memory
+        qw = [torch.cat([t, t[: t.shape[0] // 8]]).contiguous() for t in qw]
     sc = [torch.from_numpy(base.scales).to(dev).clone() for c in range(copies)]
     qz = [torch.from_numpy(base.qzeros).to(dev).clone() for c in range(copies)]
     out = torch.empty((m, n), dtype=torch.float16, device=dev)

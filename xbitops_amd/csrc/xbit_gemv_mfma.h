@@ -125,6 +125,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   static_assert(!MULTI || (GUARD && !SPLIT && ABLATE == 0), "fused launches use the guarded, unsplit build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
+  constexpr bool PACKED_PROBE = (ABLATE & 2048) != 0;
+  constexpr bool PROBE_META = (ABLATE & 4096) != 0;
   constexpr bool WFIRST = (ABLATE & 1024) != 0;  // measurement: first weight rows issued ahead of the activation slice
   constexpr int LK = 64 / NL;                // k-slots per wave
   constexpr int RS = NL < 16 ? 16 / NL : 1;  // NL = 8: k-slots sharing one MFMA k-octet (in different column slots)
@@ -145,7 +147,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   constexpr int CHK = Unpack<BITS>::kChunkK;  // k per chunk
   constexpr int CPT = CHK / 8;               // 16-byte loads / LDS stores per task
   constexpr int NTASK = MT * LK * UB * (32 / CHK);
-  constexpr int ROUNDS = (NTASK + 63) / 64;
+  // Measurement build 8192: the slice of an 8-16 row pass cut into UB parts (k-block j of every k-slot), part j+1
+  // requested and part j staged in front of block j's steps instead of the whole slice in front of the first MFMA.
+  // Measured slower (4096x11008 M=16: 9.8 us against 9.0, w3 9.7 / 8.9, w6 12.3 / 11.2; profiles/r02/
+  // sweep_16_row_pass_pipelined_staging.txt): every part boundary is another full wait on the in-order load queue.
+  constexpr bool PIPE_ACT = MT >= 8 && UB > 1 && (ABLATE & 8192) != 0;
+  constexpr int PARTS = PIPE_ACT ? UB : 1;
+  constexpr int TB = NTASK / PARTS;        // tasks per part
+  constexpr int ROUNDS = (TB + 63) / 64;   // rounds per part
 
   // 16-row passes: the reduction scratch reuses the activation region (one extra barrier), which
   // is what lets 4 k-blocks per lane fit in the 160 KB of LDS (139 KB of activations at NW = 8)
@@ -203,7 +212,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const uint32_t row_bytes = n_ * 4u;  // one packed row
 
-  const rsrc_t r_w = make_rsrc(qweight_, p.kw * row_bytes);
+  const rsrc_t r_w = make_rsrc(qweight_, PACKED_PROBE ? (p.kw + p.kw / 8u) * row_bytes : p.kw * row_bytes);  // probe: tools/gemv_sweep.py allocates the slack
   const rsrc_t r_s = make_rsrc(scales_, p.groups * n_ * 2u);
   const rsrc_t r_z = make_rsrc(qzeros_, p.groups * zw_ * 4u);
   const rsrc_t r_a = make_rsrc(p.a, p.m * p.k * 2u);
@@ -223,7 +232,17 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     //     the scalar offset.  Rows past the end of qweight read 0 (their activations are 0 as well).
     RowLoad<CPL, NT, ((ABLATE & 256) ? 16 : 0) | ((ABLATE & 512) ? 1 : 0)> w[UB][BITS];
     uint32_t lane_off = (bt * (uint32_t)(UB * BITS)) * row_bytes + col * 4u;
+    // measurement (wrong results): the addresses a tile-contiguous layout [tile][wave batch group][row][k-slot][cw columns]
+    // would have; cw (p.splits) = real columns per tile <= CN, PROBE_META: one more row per batch holding (scale | -z*s)
+    constexpr uint32_t PROBE_R = (uint32_t)(UB * BITS + (PROBE_META ? 1 : 0));
+    const uint32_t cw = PACKED_PROBE ? p.splits : (uint32_t)CN;
+    if constexpr (PACKED_PROBE) {
+      lane_off = tile * (((p.batches + LK - 1) / LK) * PROBE_R * LK * cw * 4u) + (((wb / LK) * (PROBE_R * LK) + (uint32_t)kl) * cw + (uint32_t)(nl * CPL)) * 4u;
+      if ((uint32_t)(nl * CPL) >= cw) lane_off = kOob;
+    }
     if (GUARD && !active) lane_off = kOob;
+    RowLoad<CPL, NT, 0> probe_meta;
+    if constexpr (PROBE_META) probe_meta.load(r_w, lane_off, 0);
     using LS = LoadSchedule<BITS, UB, LA>;
     auto issue_range = [&](auto from_c, auto to_c) {
       constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
@@ -233,7 +252,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
 #pragma unroll
           for (int c = 0; c < CPL; ++c) w[j][i].v[c] = lane_off * (uint32_t)(2 * c + 3) + (uint32_t)idx * 0x9E3779B1u;
         } else {
-          w[j][i].load(r_w, lane_off, (uint32_t)idx * row_bytes);
+          w[j][i].load(r_w, lane_off, PACKED_PROBE ? (uint32_t)(idx + (PROBE_META ? 1 : 0)) * (uint32_t)(LK * 4) * cw : (uint32_t)idx * row_bytes);
         }
       });
     };
@@ -246,22 +265,42 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
 
     // (1) activation slice of this wave (oldest loads in the vmcnt queue).  Rows >= M fall off the
     //     end of the buffer and read 0; k >= K must be forced out of range (it would alias row m+1).
-    u32x4_t hraw[ROUNDS][CPT];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int s = (lane + 64 * r) % NTASK;
-      const int mi = s / (LK * UB * (32 / CHK)), ch = s % (LK * UB * (32 / CHK));
-      const uint32_t k0 = wb * (uint32_t)(UB * 32) + (uint32_t)(ch * CHK);
-      uint32_t aoff = ((m0 + mi) * p.k + k0) * 2u;
-      if (GUARD && (k0 >= k_end || m0 + mi >= p.m)) aoff = kOob;  // k % 8 == 0: chunks are all-in or all-out
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        uint32_t o = aoff + 16u * q;
-        if (GUARD && CPT > 1 && k0 + 8u * q >= k_end) o = kOob;
-        if constexpr (ABLATE & 32) hraw[r][q] = u32x4_t{o, o + 1u, o + 2u, o + 3u};  // measurement: no activation loads
-        else hraw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
+    u32x4_t hraw[PARTS][ROUNDS][CPT];
+    // task t of part `part`: chunk `cib` of k-block `blk` (of the wave's LK * UB) of row `mi`
+    auto act_task = [&](int part, int r, int& mi, int& blk, int& cib) {
+      const int t = (lane + 64 * r) % TB;
+      if constexpr (PIPE_ACT) {
+        constexpr int per = LK * (32 / CHK);
+        mi = t / per;
+        blk = ((t % per) / (32 / CHK)) * UB + part;
+        cib = t % (32 / CHK);
+      } else {
+        constexpr int per = LK * UB * (32 / CHK);
+        mi = t / per;
+        blk = (t % per) / (32 / CHK);
+        cib = t % (32 / CHK);
       }
-    }
+    };
+    auto act_issue = [&](auto part_c) {
+      constexpr int part = decltype(part_c)::value;
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        int mi, blk, cib;
+        act_task(part, r, mi, blk, cib);
+        const uint32_t k0 = wb * (uint32_t)(UB * 32) + (uint32_t)(blk * 32 + cib * CHK);
+        uint32_t aoff = ((m0 + mi) * p.k + k0) * 2u;
+        if (GUARD && (k0 >= k_end || m0 + mi >= p.m)) aoff = kOob;  // k % 8 == 0: chunks are all-in or all-out
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+          uint32_t o = aoff + 16u * q;
+          if (GUARD && CPT > 1 && k0 + 8u * q >= k_end) o = kOob;
+          if constexpr (ABLATE & 32) hraw[part][r][q] = u32x4_t{o, o + 1u, o + 2u, o + 3u};  // measurement: no activation loads
+          else hraw[part][r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
+        }
+      }
+    };
+    act_issue(std::integral_constant<int, 0>{});
+    if constexpr (PARTS > 1) act_issue(std::integral_constant<int, 1>{});
 
     // (2) scale and zero-point of the batch's group (one group per batch on this path); a group
     //     index past the end reads scale 0, which makes every weight of that lane exactly 0
@@ -272,7 +311,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       const uint32_t h0 = gi * n_ + col;
       uint32_t soff = (h0 & ~1u) * 2u;
       if (GUARD && !active) soff = kOob;
-      if constexpr (ABLATE & 64) {  // measurement: no scale loads
+      if constexpr (PROBE_META) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) sbits[c] = 0x1C00u | (probe_meta.v[c] & 0x3FFu);
+      } else if constexpr (ABLATE & 64) {  // measurement: no scale loads
         sbits[0] = 0x1C00u + (soff & 0xFFu);
         sbits[1] = sbits[0] + 1u;
         if constexpr (CPL > 2) sbits[2] = sbits[0] + 2u;
@@ -295,7 +337,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     {
       const uint32_t bit = col * BITS, sh = bit & 31u;
       const uint32_t zoff = (gi * zw_ + (bit >> 5)) * 4u;
-      if constexpr (ABLATE & 64) {
+      if constexpr (PROBE_META) {
+        zwin = probe_meta.v[CPL - 1] >> 16;
+      } else if constexpr (ABLATE & 64) {
         zwin = zoff >> sh;  // measurement: no zero-point loads
       } else if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
         zwin = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0) >> sh;  // the CPL fields never straddle a word
@@ -315,42 +359,45 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     }
 
     // (4) permute each chunk into pair order and park it in this wave's LDS region (every lane
-    //     stores; lanes beyond NTASK repeat a task with identical data)
+    //     stores; lanes beyond the part's tasks repeat a task with identical data)
+    auto act_stage = [&](auto part_c) {
+      constexpr int part = decltype(part_c)::value;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int s = (lane + 64 * r) % NTASK;
-      const int mi = s / (LK * UB * (32 / CHK)), ch = s % (LK * UB * (32 / CHK));
-      const int blk = ch / (32 / CHK), cib = ch % (32 / CHK);  // k-block of the slice, chunk inside it
-      uint32_t h[CHK / 2];
+      for (int r = 0; r < ROUNDS; ++r) {
+        int mi, blk, cib;
+        act_task(part, r, mi, blk, cib);
+        uint32_t h[CHK / 2];
 #pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        h[4 * q + 0] = hraw[r][q].x;
-        h[4 * q + 1] = hraw[r][q].y;
-        h[4 * q + 2] = hraw[r][q].z;
-        h[4 * q + 3] = hraw[r][q].w;
-      }
-      uint32_t* dst = my_act + ((blk / UB) * MT + mi) * KLS + (blk % UB) * 16 + cib * (CHK / 2);
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        uint32_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // pair (4q+e) of this chunk; pair_k is periodic in the chunk, so chunk 0's table serves all
-          const int pr = 4 * q + e;
-          const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
-          static_assert(Unpack<BITS>::pair_k(CHK / 2 - 1, 1) < CHK, "pairs stay inside a chunk");
-          const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) |
-                               ((uint32_t)(4 + 2 * (khi & 1)) << 16) | ((uint32_t)(5 + 2 * (khi & 1)) << 24);
-          o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+        for (int q = 0; q < CPT; ++q) {
+          h[4 * q + 0] = hraw[part][r][q].x;
+          h[4 * q + 1] = hraw[part][r][q].y;
+          h[4 * q + 2] = hraw[part][r][q].z;
+          h[4 * q + 3] = hraw[part][r][q].w;
         }
-        if constexpr (!(ABLATE & 32)) *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
-        else asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+        uint32_t* dst = my_act + ((blk / UB) * MT + mi) * KLS + (blk % UB) * 16 + cib * (CHK / 2);
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+          uint32_t o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // pair (4q+e) of this chunk; pair_k is periodic in the chunk, so chunk 0's table serves all
+            const int pr = 4 * q + e;
+            const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
+            static_assert(Unpack<BITS>::pair_k(CHK / 2 - 1, 1) < CHK, "pairs stay inside a chunk");
+            const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) |
+                                 ((uint32_t)(4 + 2 * (khi & 1)) << 16) | ((uint32_t)(5 + 2 * (khi & 1)) << 24);
+            o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+          }
+          if constexpr (!(ABLATE & 32)) *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
+          else asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+        }
       }
-    }
-    // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    act_stage(std::integral_constant<int, 0>{});
     if constexpr (ABLATE & 8) {
       if (b0 == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();  // activations staged
       __builtin_amdgcn_sched_barrier(0);
@@ -379,8 +426,16 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       constexpr bool FAST = decltype(fast_c)::value;
       static_for<UB * 4>([&](auto step_c) {
         constexpr int step = decltype(step_c)::value, j = step / 4, oct = step % 4;
+        if constexpr (PIPE_ACT && oct == 0 && j >= 1 && j + 1 < UB) {
+          act_issue(std::integral_constant<int, (j + 1 < UB ? j + 1 : 0)>{});  // part j+1 goes out one k-block ahead of its use
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (LA > 0 && step > 0) {
           issue_range(std::integral_constant<int, LS::issued_before(step - 1)>{}, std::integral_constant<int, LS::issued_before(step)>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (PIPE_ACT && oct == 0 && j >= 1) {
+          act_stage(std::integral_constant<int, (j < PARTS ? j : 0)>{});  // waits for part j only: the younger weight rows stay in flight
           __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t wc[CPL][BITS];
@@ -654,6 +709,18 @@ int launch_la(GemvParams p, hipStream_t stream) {
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
 }
 
+// measurement-only: tile-contiguous address probe, `cw` real columns per tile (0 = the full 16*CPL)
+template <int BITS, int UB, int CPL, int NL, int NW, int ABLATE, int LA>
+int launch_probe(GemvParams p, hipStream_t stream, uint32_t cw) {
+  constexpr int CN = NL * CPL;
+  p.splits = cw ? cw : (uint32_t)CN;
+  p.tiles = (p.n + p.splits - 1) / p.splits;
+  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
+  if ((uint64_t)p.tiles * CN > p.n + 4096u) return XBIT_ERR_SHAPE;
+  dim3 grid(p.tiles, p.m), block(64 * NW);
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
+}
+
 // measurement-only launch of the 16-row pass (NL = 16, 8 waves) with ABLATE bits
 template <int BITS, int UB, int CPL, int ABLATE>
 int launch_rows16_ablate(GemvParams p, hipStream_t stream) {
@@ -779,6 +846,8 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     if (variant == 184 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32 | 128>(p, stream);      // ... and no LDS reduction
     if (variant == 185 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2 | 32 | 128>(p, stream);  // ... and no arithmetic: loads only
     if (variant == 186 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 128>(p, stream);           // full kernel minus the LDS reduction
+    if (variant == 188 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8192>(p, stream);          // activation slice fetched and staged k-block by k-block inside the step loop
+    if (variant == 187 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2048>(p, stream);          // tile-contiguous addresses (wrong results)
     if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
         case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
@@ -839,6 +908,27 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 164: return launch_m1<BITS, 4, 3, 16, 8, true, 8>(p, stream);        // nt, lookahead 8
           case 165: return launch_la<BITS, 4, 3, 16, 8, 256, 6>(p, stream);         // sc1, lookahead 6
           case 166: return launch_la<BITS, 4, 3, 16, 8, 512, 6>(p, stream);         // sc0, lookahead 6
+          case 210: return launch_probe<BITS, 4, 3, 16, 8, 2048, 4>(p, stream, 0);        // tile-contiguous addresses (wrong results), 48-column tiles
+          case 211: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 64, 4>(p, stream, 0);   // ... and no scale / zero loads
+          case 212: return launch_probe<BITS, 4, 4, 16, 8, 2048, 4>(p, stream, 0);        // ... 64-column tiles
+          case 213: return launch_probe<BITS, 2, 2, 8, 8, 2048, 4>(p, stream, 0);         // ... 16-column tiles (8 lanes x 8 B x 8 k-slots), whole K
+          case 214: return launch_la<BITS, 2, 2, 8, 8, 0, 4>(p, stream);                  // the same tiles in the reference layout
+          case 215: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 2, 4>(p, stream, 0);    // tile-contiguous, loads only
+          case 216: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 2 | 32 | 64 | 128, 0>(p, stream, 0);  // ... none of the small operands, all loads up front
+          case 218: return launch_probe<BITS, 4, 3, 16, 8, 2048, 6>(p, stream, 0);        // lookahead 6
+          case 219: return launch_probe<BITS, 4, 3, 16, 8, 2048, 3>(p, stream, 0);        // lookahead 3
+          // ... with the scale and -z*s of a batch as one more row of the stream (no separate scale / zero loads)
+          case 220: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 4>(p, stream, 0);
+          // ... and tiles of n/256 real columns, one per CU (4096x11008: 43 columns)
+          case 221: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 4>(p, stream, (p.n + 255u) / 256u);
+          case 222: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 64, 4>(p, stream, (p.n + 255u) / 256u);
+          case 223: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 5>(p, stream, (p.n + 255u) / 256u);
+          case 224: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 6>(p, stream, (p.n + 255u) / 256u);
+          case 225: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64 | 2, 4>(p, stream, (p.n + 255u) / 256u);  // loads only
+          case 226: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64 | 2 | 32 | 128, 0>(p, stream, (p.n + 255u) / 256u);  // pure stream
+          // 16-slot tiles (8 lanes x 8 B x 8 k-slots) of n/256 real columns (8192x3584: 14, 4096x4096: 16), whole K
+          case 227: return launch_probe<BITS, 2, 2, 8, 8, 2048 | 4096 | 64, 4>(p, stream, (p.n + 255u) / 256u);
+          case 228: return launch_probe<BITS, 2, 2, 8, 8, 2048 | 4096 | 64, 6>(p, stream, (p.n + 255u) / 256u);
           case 150: return launch_la<BITS, 4, 3, 16, 8, 2 | 32, 4>(p, stream);              // loads only, no activation staging
           case 151: return launch_la<BITS, 4, 3, 16, 8, 2 | 64, 4>(p, stream);              // loads only, no scale / zero loads
           case 152: return launch_la<BITS, 4, 3, 16, 8, 2 | 128, 4>(p, stream);             // loads only, no LDS reduction
