@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of the GEMV kernel (stamped measurement build, variant 63): when did each
+"""Per-wave timeline of the GEMV kernel (stamped measurement builds: variant 63 = 1 row, 193 = 4 rows, 189 = 16 rows): when did each
 wave start, finish issuing its loads, finish staging, issue its last MFMA, pass the barrier, end.
     python tools/gemv_trace.py [--shape K,N]
 """
@@ -16,8 +16,9 @@ sys.path.insert(0, ROOT)
 from xbitops_amd import _lib, synth  # noqa: E402
 
 NAMES = ["wave start", "loads issued", "act staged", "last MFMA issued", "past barrier", "wave end"]
-NW = {63: 8}
-CN = {63: 48}
+NW = {63: 8, 189: 8, 193: 8}
+CN = {63: 48, 189: 48, 193: 48}
+ROWS = {63: 1, 189: 16, 193: 4}  # activation rows of the stamped build
 
 
 def main():
@@ -28,17 +29,18 @@ def main():
     dev = torch.device("cuda", 0)
     lib = _lib.load_tuning()  # the stamped kernel lives in the measurement build only
     k, n = [int(x) for x in args.shape.split(",")]
-    bits, g, m = 4, 128, 1
-    nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
+    bits, g = 4, 128
+    nbytes = synth.algorithmic_bytes(k, n, bits, g, 1)
     copies = (512 << 20) // nbytes + 2
-    base = synth.make_problem(k, n, bits, g, m=m, seed=1)
-    act = torch.from_numpy(base.act).to(dev)
+    base = synth.make_problem(k, n, bits, g, m=1, seed=1)
     qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
     sc = torch.from_numpy(base.scales).to(dev)
     qz = torch.from_numpy(base.qzeros).to(dev)
-    out = torch.empty((m, n), dtype=torch.float16, device=dev)
     sp = torch.cuda.current_stream(dev).cuda_stream
     for v in [int(x) for x in args.variants.split(",")]:
+        m = ROWS[v]
+        act = torch.from_numpy(synth.make_problem(k, n, bits, g, m=m, seed=1).act).to(dev)
+        out = torch.empty((m, n), dtype=torch.float16, device=dev)
         waves = ((n + CN[v] - 1) // CN[v]) * NW[v]
         trace = torch.zeros((waves, 8), dtype=torch.int64, device=dev)
         opts = _lib.GemvOptions(variant=v, trace=trace.data_ptr())

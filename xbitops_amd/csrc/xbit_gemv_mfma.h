@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   static_assert(!MULTI || (GUARD && !SPLIT && ABLATE == 0), "fused launches use the guarded, unsplit build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
+  constexpr bool WAITFIRST = (ABLATE & 131072) != 0;
   constexpr bool PACKED_PROBE = (ABLATE & 2048) != 0;
   constexpr bool PROBE_META = (ABLATE & 4096) != 0;
   constexpr bool WFIRST = (ABLATE & 1024) != 0;  // measurement: first weight rows issued ahead of the activation slice
@@ -147,12 +148,17 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   constexpr int CHK = Unpack<BITS>::kChunkK;  // k per chunk
   constexpr int CPT = CHK / 8;               // 16-byte loads / LDS stores per task
   constexpr int NTASK = MT * LK * UB * (32 / CHK);
-  // Measurement build 8192: the slice of an 8-16 row pass cut into UB parts (k-block j of every k-slot), part j+1
-  // requested and part j staged in front of block j's steps instead of the whole slice in front of the first MFMA.
-  // Measured slower (4096x11008 M=16: 9.8 us against 9.0, w3 9.7 / 8.9, w6 12.3 / 11.2; profiles/r02/
-  // sweep_16_row_pass_pipelined_staging.txt): every part boundary is another full wait on the in-order load queue.
-  constexpr bool PIPE_ACT = MT >= 8 && UB > 1 && (ABLATE & 8192) != 0;
-  constexpr int PARTS = PIPE_ACT ? UB : 1;
+  // 8-16 rows per pass: the slice is 8-16 loads per lane and the CU's vector-memory path moves 64 B a clock, so
+  // fetching it whole in front of the first weight rows holds the HBM stream back by ~0.85 us (per-wave timelines,
+  // tools/gemv_trace.py --variants 189: first weight row out at 2.1 us against 0.7 at one row).  Measurement builds
+  // cut the slice into parts of JP k-blocks of every k-slot, part 0 in front of the first weight rows, part 1
+  // behind them, part p staged in front of its first step: 16384 = JP 2 (128 contiguous bytes per row and k-slot),
+  // 8192 = JP 1 (64 B).  Both measured SLOWER than the whole slice up front (4096x11008 M=16, one box: 9.16 and
+  // 9.8 us against 8.92; profiles/r02/sweep_16_row_pass_*_staging.txt): every part boundary is one more full wait
+  // on the in-order load queue, and that costs more than the later start of the stream.
+  constexpr int JP = (MT >= 8 && UB == 4) ? ((ABLATE & 8192) ? 1 : (ABLATE & 16384) ? 2 : UB) : UB;
+  constexpr bool PIPE_ACT = JP < UB;
+  constexpr int PARTS = UB / JP;
   constexpr int TB = NTASK / PARTS;        // tasks per part
   constexpr int ROUNDS = (TB + 63) / 64;   // rounds per part
 
@@ -269,17 +275,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     // task t of part `part`: chunk `cib` of k-block `blk` (of the wave's LK * UB) of row `mi`
     auto act_task = [&](int part, int r, int& mi, int& blk, int& cib) {
       const int t = (lane + 64 * r) % TB;
-      if constexpr (PIPE_ACT) {
-        constexpr int per = LK * (32 / CHK);
-        mi = t / per;
-        blk = ((t % per) / (32 / CHK)) * UB + part;
-        cib = t % (32 / CHK);
-      } else {
-        constexpr int per = LK * UB * (32 / CHK);
-        mi = t / per;
-        blk = (t % per) / (32 / CHK);
-        cib = t % (32 / CHK);
-      }
+      constexpr int per = LK * JP * (32 / CHK);  // tasks of one row: LK k-slots x JP k-blocks x chunks (JP == UB: the whole slice)
+      mi = t / per;
+      blk = ((t % per) / (JP * (32 / CHK))) * UB + part * JP + (t % (JP * (32 / CHK))) / (32 / CHK);
+      cib = t % (32 / CHK);
     };
     auto act_issue = [&](auto part_c) {
       constexpr int part = decltype(part_c)::value;
@@ -300,7 +299,6 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       }
     };
     act_issue(std::integral_constant<int, 0>{});
-    if constexpr (PARTS > 1) act_issue(std::integral_constant<int, 1>{});
 
     // (2) scale and zero-point of the batch's group (one group per batch on this path); a group
     //     index past the end reads scale 0, which makes every weight of that lane exactly 0
@@ -350,6 +348,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     }
 
     if constexpr (!WFIRST) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, LS::issued_before(0)>{});
+    if constexpr (PARTS > 1) act_issue(std::integral_constant<int, 1>{});  // behind the first weight rows: the HBM stream starts first
     // Pin the issue order act -> scale/zero -> weights (WFIRST: first weights -> act -> scale/zero): each
     // wait below then leaves every younger load in flight (vmcnt retires in order).
     __builtin_amdgcn_sched_barrier(0);
@@ -426,16 +425,24 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       constexpr bool FAST = decltype(fast_c)::value;
       static_for<UB * 4>([&](auto step_c) {
         constexpr int step = decltype(step_c)::value, j = step / 4, oct = step % 4;
-        if constexpr (PIPE_ACT && oct == 0 && j >= 1 && j + 1 < UB) {
-          act_issue(std::integral_constant<int, (j + 1 < UB ? j + 1 : 0)>{});  // part j+1 goes out one k-block ahead of its use
+        if constexpr (PIPE_ACT && oct == 0 && j >= JP && j % JP == 0 && j / JP + 1 < PARTS) {
+          act_issue(std::integral_constant<int, (j / JP + 1 < PARTS ? j / JP + 1 : 0)>{});  // the part after this one goes out one part ahead of its use
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (LA > 0 && step > 0) {
+          if constexpr (WAITFIRST && LS::issued_before(step) > LS::issued_before(step - 1)) {
+            // wait for the rows this step consumes BEFORE issuing the next ones: the new loads then go out the moment
+            // the data lands instead of one step's arithmetic later (a touch of the last needed row makes the
+            // compiler place its s_waitcnt here)
+            constexpr int last = LS::need(step) - 1;
+            asm volatile("" ::"v"(w[last / BITS][last % BITS].v[0]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
           issue_range(std::integral_constant<int, LS::issued_before(step - 1)>{}, std::integral_constant<int, LS::issued_before(step)>{});
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (PIPE_ACT && oct == 0 && j >= 1) {
-          act_stage(std::integral_constant<int, (j < PARTS ? j : 0)>{});  // waits for part j only: the younger weight rows stay in flight
+        if constexpr (PIPE_ACT && oct == 0 && j >= JP && j % JP == 0) {
+          act_stage(std::integral_constant<int, (j / JP < PARTS ? j / JP : 0)>{});  // waits for this part only: the younger weight rows stay in flight
           __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t wc[CPL][BITS];
@@ -538,7 +545,19 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   for (int e = tid; e < MT * CN; e += 64 * nwaves) {
     const int m = e / CN, c = e % CN;
     float sum = 0.f;
-    for (int v = 0; v < nwaves * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
+    if constexpr (ABLATE & 32768) {  // measurement: compile-time bound, predicated - every read goes out at once.  Measured SLOWER
+#pragma unroll                         // (4096x11008: 6.80 against 6.66 us at 1 row, 9.45 against 8.92 at 16; sweep_16_row_pass_two_part_staging.txt)
+      for (int v = 0; v < NW * RS; ++v)
+        if (v < nwaves * RS) sum += s_red[(v * MT + m) * CN + c];
+    } else if constexpr (ABLATE & 65536) {  // measurement: every slot read unconditionally (inside the scratch), absent waves' values deselected
+#pragma unroll
+      for (int v = 0; v < NW * RS; ++v) {
+        const float x = s_red[(v * MT + m) * CN + c];
+        sum += v < nwaves * RS ? x : 0.f;
+      }
+    } else {
+      for (int v = 0; v < nwaves * RS; ++v) sum += s_red[(v * MT + m) * CN + c];
+    }
     const uint32_t n_out = tile * CN + c, row = m0 + m;
     const bool valid = !GUARD || (n_out < n_ && row < p.m);
     if constexpr (SPLIT) {
@@ -661,9 +680,32 @@ struct SplitPlan {
   int cpl = 0;
   uint32_t splits = 0;
 };
-inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits) {
+// Shapes where a measured plan beats the scored one by >= 5 % (4-bit, one row; profiles/r02/sweep_split_plans_fine.txt:
+// every split factor 2..12 x both tile widths on 14 small-N shapes - on the other 11 the score is within 2.6 % of
+// the best).  All three are down-projections whose K is not a power of two: six K ranges of 15-18 batches run as
+// 4-5-wave workgroups, three or more per CU, where the score would take wide tiles with 4-6 waves per CU.
+struct TunedPlan {
+  uint32_t k, n;
+  int cpl;
+  uint32_t splits;
+};
+constexpr TunedPlan kTunedPlans4[] = {
+    {11008, 4096, 2, 6},  // Llama-7B down_proj:       7.64 us against 8.28
+    {13824, 5120, 2, 6},  // Llama-13B down_proj:     10.52 against 11.12
+    {13824, 2560, 2, 6},  // ... its 2-way column shard: 7.20 against 8.00
+};
+
+inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int bits = 0) {
   SplitPlan plan;
   if (p.m > 4 || forced_splits == 1) return plan;
+  if (forced_splits == 0 && bits == 4 && p.m == 1 && p.groupsize == 128u) {
+    for (const TunedPlan& t : kTunedPlans4)
+      if (t.k == p.k && t.n == p.n) {
+        plan.cpl = t.cpl;
+        plan.splits = t.splits;
+        return plan;
+      }
+  }
   const uint32_t kblocks = (p.k + 31) / 32, batches = (kblocks + ub - 1) / ub;
   const uint32_t tiles32 = (p.n + 31) / 32;
   if (forced_splits > 0) {
@@ -722,13 +764,13 @@ int launch_probe(GemvParams p, hipStream_t stream, uint32_t cw) {
 }
 
 // measurement-only launch of the 16-row pass (NL = 16, 8 waves) with ABLATE bits
-template <int BITS, int UB, int CPL, int ABLATE>
+template <int BITS, int UB, int CPL, int ABLATE, int MT = 16>
 int launch_rows16_ablate(GemvParams p, hipStream_t stream) {
   constexpr int CN = 16 * CPL;
   p.tiles = (p.n + CN - 1) / CN;
   p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  dim3 grid(p.tiles, (p.m + 15) / 16), block(64 * sweep_waves(p.batches, 4, 8));
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, 8, 16, false, true, ABLATE, lookahead_for<BITS>()>, grid, block, stream, p);
+  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * sweep_waves(p.batches, 4, 8));
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, 8, MT, false, true, ABLATE, lookahead_for<BITS>()>, grid, block, stream, p);
 }
 
 // rows per pass: 1, 4, 8 or 16 (fewer staged rows = less LDS traffic); NL = 8 / 32 tiles take <= 8 rows.
@@ -846,6 +888,15 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     if (variant == 184 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32 | 128>(p, stream);      // ... and no LDS reduction
     if (variant == 185 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2 | 32 | 128>(p, stream);  // ... and no arithmetic: loads only
     if (variant == 186 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 128>(p, stream);           // full kernel minus the LDS reduction
+    if (variant == 189 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8>(p, stream);             // stamped (tools/gemv_trace.py --m 16)
+    if (variant == 193 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 8, 4>(p, stream);  // 4-row pass, stamped
+    if (variant == 194 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 2 | 32 | 128, 4>(p, stream);  // 4-row pass, loads only
+    if (variant == 195 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 128, 4>(p, stream);  // 4-row pass minus the LDS reduction
+    if (variant == 196 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 32, 4>(p, stream);   // 4-row pass minus the activation loads
+    if (variant == 198 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 16384 | 32768>(p, stream);  // ... and the reduction reads unrolled and predicated
+    if (variant == 199 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32768>(p, stream);          // whole slice, reduction reads unrolled and predicated
+    if (variant == 200 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 65536>(p, stream);         // whole slice, reduction reads unconditional + select
+    if (variant == 197 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 16384>(p, stream);         // activation slice in two parts (k-blocks 0-1, 2-3), the second behind the first weight rows
     if (variant == 188 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8192>(p, stream);          // activation slice fetched and staged k-block by k-block inside the step loop
     if (variant == 187 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2048>(p, stream);          // tile-contiguous addresses (wrong results)
     if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
@@ -908,6 +959,22 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 164: return launch_m1<BITS, 4, 3, 16, 8, true, 8>(p, stream);        // nt, lookahead 8
           case 165: return launch_la<BITS, 4, 3, 16, 8, 256, 6>(p, stream);         // sc1, lookahead 6
           case 166: return launch_la<BITS, 4, 3, 16, 8, 512, 6>(p, stream);         // sc0, lookahead 6
+          // 128-column tiles (the 8192x28672 path: 32 lanes x 16 B, nontemporal): lookahead and workgroup size
+          case 236: return launch_m1<BITS, 4, 4, 32, 16, true, 2>(p, stream);
+          case 237: return launch_m1<BITS, 4, 4, 32, 16, true, 6>(p, stream);
+          case 238: return launch_m1<BITS, 4, 4, 32, 16, true, 8>(p, stream);
+          case 239: return launch_m1<BITS, 4, 4, 32, 8, true, 4>(p, stream);
+          case 240: return launch_m1<BITS, 4, 4, 32, 8, true, 6>(p, stream);
+          case 241: return launch_m1<BITS, 4, 4, 32, 8, true, 8>(p, stream);
+          case 242: return launch_m1<BITS, 4, 4, 16, 8, true, 6>(p, stream);   // 64-column tiles, nontemporal, lookahead 6
+          case 243: return launch_m1<BITS, 4, 4, 16, 8, true, 8>(p, stream);
+          case 231: return launch_la<BITS, 4, 3, 16, 8, 131072, 4>(p, stream);  // wait for a step's rows before issuing the next loads, lookahead 4
+          case 232: return launch_la<BITS, 4, 3, 16, 8, 131072, 5>(p, stream);  // ... lookahead 5 (the same 5 rows outstanding at most)
+          case 233: return launch_la<BITS, 4, 3, 16, 8, 131072, 6>(p, stream);
+          case 234: return launch_la<BITS, 4, 3, 16, 8, 131072, 8>(p, stream);
+          case 235: return launch_la<BITS, 4, 3, 16, 8, 0, 5>(p, stream);       // lookahead 5, production order
+          case 230: return launch_la<BITS, 4, 3, 16, 8, 65536, 4>(p, stream);   // reduction reads unconditional + select
+          case 229: return launch_la<BITS, 4, 3, 16, 8, 32768, 4>(p, stream);   // reduction reads unrolled and predicated
           case 210: return launch_probe<BITS, 4, 3, 16, 8, 2048, 4>(p, stream, 0);        // tile-contiguous addresses (wrong results), 48-column tiles
           case 211: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 64, 4>(p, stream, 0);   // ... and no scale / zero loads
           case 212: return launch_probe<BITS, 4, 4, 16, 8, 2048, 4>(p, stream, 0);        // ... 64-column tiles
@@ -956,7 +1023,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
 #endif  // XBIT_TUNING
     // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
     {
-      SplitPlan plan = plan_split(p, UBMAX, opts.split);
+      SplitPlan plan = plan_split(p, UBMAX, opts.split, BITS);
       if (variant == 206 && plan.splits >= 2) {  // measurement: 32-column tiles read as 8 lanes x 16 B (NL = 8), split as planned
         const uint32_t tiles = (p.n + 31u) / 32u;
         const size_t slots = (size_t)tiles * 32u;
