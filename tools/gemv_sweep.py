@@ -52,7 +52,15 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, spli
 
     def fn(i):
         c = i % copies
-        st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, opts)
+        o = opts
+        if variant == 254:  # prefetch copy c with a separate launch of the prefetch workgroups alone, then time the production-shape kernel on it
+            pre = _lib.GemvOptions(variant=251, workspace=qw[c].data_ptr(), workspace_bytes=qw[0].numel() * 4)
+            st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[(c + 3) % copies].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, pre)
+            assert st == 0, st
+            o = _lib.GemvOptions(variant=15)
+        if 250 <= variant <= 253 or 255 <= variant <= 258:  # prototype: this call also prefetches the NEXT call's packed weights (passed in options.workspace)
+            o = _lib.GemvOptions(variant=variant, workspace=qw[(c + 1) % copies].data_ptr(), workspace_bytes=qw[0].numel() * 4)
+        st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, o)
         assert st == 0, st
 
     avg, med, mn = measure(lib, fn, iters)

@@ -172,7 +172,49 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   float* const s_red = reinterpret_cast<float*>(s_lds + (ALIAS ? 0 : NW * ACT_DW));
 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / NL, nl = lane % NL;
-  const int nwaves = (int)(blockDim.x >> 6);   // <= NW
+  // HELPER (measurement build 524288): the workgroup's LAST wave computes nothing; it requests one dword of every
+  // 128-byte line of the tile, in the order the compute waves consume the packed rows, so that HBM -> L2 runs at
+  // the rate of a dependence-free read while the compute waves' own loads find their lines in (or on the way to) L2
+  constexpr bool HELPER = (ABLATE & 524288) != 0;
+  const int nwaves = (int)(blockDim.x >> 6) - (HELPER ? 1 : 0);   // compute waves, <= NW
+  const bool helper = HELPER && wv == nwaves;
+  if constexpr (ABLATE & 262144) {
+    // Prototype (measurement build): 256 more workgroups in the grid touch one dword of every 128-byte line of the
+    // NEXT call's packed weights (p.acc, same shape) while this call computes, so that the next call finds them in
+    // L2 / the Infinity Cache.  Workgroup (XCD x = blockIdx & 7, j of 32) takes rows [j*kw/32, (j+1)*kw/32) of the
+    // column stripe that XCD x's tiles cover - the lines land in the L2 that will read them.
+    if (blockIdx.x >= p.tiles) {
+      const uint32_t pb = blockIdx.x - p.tiles, x = blockIdx.x & 7u, j = pb >> 3;
+      const uint32_t q = p.tiles >> 3, r = p.tiles & 7u;
+      const uint32_t t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1u : 0u);
+      const uint32_t row_b = p.n * 4u, lo = (t0 * (uint32_t)(NL * CPL) * 4u) & ~127u;
+      uint32_t hi = (t0 + cnt) * (uint32_t)(NL * CPL) * 4u;
+      hi = hi < row_b ? hi : row_b;
+      const uint32_t lpr = hi > lo ? (hi - lo + 127u) / 128u : 0u;
+      const uint32_t r0 = (uint32_t)(((uint64_t)j * p.kw) / 32u), r1 = (uint32_t)(((uint64_t)(j + 1) * p.kw) / 32u);
+      const rsrc_t r_pf = make_rsrc(p.acc, p.kw * row_b);
+      uint32_t sum = 0;
+      if ((p.bps & 255u) == 2u) {  // flat: workgroup pb reads its 1/256 of the bytes, 16 B per lane, contiguous (no XCD affinity)
+        const uint32_t total16 = (p.kw * row_b) / 16u, per = (total16 + 255u) / 256u;
+        for (uint32_t i = (uint32_t)tid; i < per; i += blockDim.x) {
+          const uint32_t e = pb * per + i;
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r_pf, e < total16 ? e * 16u : kOob, 0, 0);
+          sum ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+      } else {
+        // pacing: wave w of the prefetch workgroup starts w * (p.bps >> 8) * 64 clocks late, so the 22 MB of line
+        // requests are spread over the launch instead of filling every memory queue in its first microsecond
+        for (uint32_t d = 0; d < (uint32_t)wv * (p.bps >> 8); ++d) __builtin_amdgcn_s_sleep(1);
+        for (uint32_t idx = (uint32_t)tid; idx < (r1 - r0) * lpr; idx += blockDim.x) {
+          const uint32_t off = (r0 + idx / lpr) * row_b + lo + (idx % lpr) * 128u;
+          sum ^= __builtin_amdgcn_raw_buffer_load_b32(r_pf, off, 0, 0);
+        }
+      }
+      asm volatile("" ::"v"(sum));
+      return;
+    }
+    if (p.splits == 7u) return;  // measurement: the prefetch workgroups alone
+  }
   const uint32_t T = (uint32_t)(LK * nwaves);  // k-batches per workgroup sweep
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
   const uint32_t tile_g = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);  // tile of the whole grid
@@ -229,7 +271,21 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABLATE & 8) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
-  for (uint32_t b0 = b_begin; b0 < b_end; b0 += T) {
+  if constexpr (HELPER) {
+    if (helper) {
+      // instruction i of batch group g: lane (b = lane >> 1, h = lane & 1) touches line h of packed row (g*32 + b)*UB*BITS + i
+      const uint32_t lo = (tile * (uint32_t)(CN * 4)) & ~127u;
+      uint32_t sum = 0;
+      for (uint32_t g0 = b_begin; g0 < b_end; g0 += 32u) {
+        const uint32_t bb = g0 + (uint32_t)(lane >> 1);
+        const uint32_t base = bb < b_end ? bb * (uint32_t)(UB * BITS) * row_bytes + lo + (uint32_t)(lane & 1) * 128u : kOob;
+#pragma unroll
+        for (int i = 0; i < UB * BITS; ++i) sum ^= __builtin_amdgcn_raw_buffer_load_b32(r_w, base, (uint32_t)i * row_bytes, 0);
+      }
+      asm volatile("" ::"v"(sum));
+    }
+  }
+  for (uint32_t b0 = helper ? b_end : b_begin; b0 < b_end; b0 += T) {
     const uint32_t wb = b0 + wv * LK;  // first batch of this wave in this sweep
     const uint32_t bt = wb + kl;       // this lane's batch
     const bool active = GUARD ? (col_ok && bt < b_end) : true;
@@ -525,7 +581,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   if constexpr (ALIAS) __syncthreads();  // every wave is done reading its activations
   // D[drow][slot]: drow = 4*(lane>>4) + r lives in register r of lane (lane>>4, slot = lane&15).
   // Keep the quadrant where the row block equals the slot's k-slot, then sum over k-slots and waves.
-  {
+  if (!helper) {
     const int slot = lane & 15, ks = slot / NL, snl = slot % NL;
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
@@ -763,6 +819,31 @@ int launch_probe(GemvParams p, hipStream_t stream, uint32_t cw) {
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
 }
 
+// measurement-only: the production M = 1 launch with one more wave per workgroup that only requests the tile's lines
+template <int BITS, int UB, int CPL, int NL, int NW, int ABLATE, int LA>
+int launch_helper(GemvParams p, hipStream_t stream) {
+  constexpr int CN = NL * CPL;
+  p.tiles = (p.n + CN - 1) / CN;
+  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
+  const uint32_t waves = sweep_waves(p.batches, 64 / NL, NW);
+  dim3 grid(p.tiles, p.m), block(64 * (waves + 1));
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW + 1, 1, false, true, ABLATE | 524288, LA>, grid, block, stream, p);
+}
+
+// measurement-only: the production M = 1 launch plus 256 prefetch workgroups for the next call's weights (opts.user_ws)
+template <int BITS, int UB, int CPL, int NL, int NW, int LA>
+int launch_with_prefetch(GemvParams p, hipStream_t stream, const GemvLaunchOpts& opts, uint32_t only = 0, uint32_t flat = 0, uint32_t pace = 0) {
+  constexpr int CN = NL * CPL;
+  if (opts.user_ws == nullptr) return XBIT_ERR_NULL_POINTER;
+  p.tiles = (p.n + CN - 1) / CN;
+  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
+  p.acc = opts.user_ws;
+  p.splits = only ? 7u : 0u;
+  p.bps = (flat ? 2u : 0u) | (pace << 8);
+  dim3 grid(p.tiles + 256u, p.m), block(64 * NW);
+  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, 262144, LA>, grid, block, stream, p);
+}
+
 // measurement-only launch of the 16-row pass (NL = 16, 8 waves) with ABLATE bits
 template <int BITS, int UB, int CPL, int ABLATE, int MT = 16>
 int launch_rows16_ablate(GemvParams p, hipStream_t stream) {
@@ -968,6 +1049,19 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 241: return launch_m1<BITS, 4, 4, 32, 8, true, 8>(p, stream);
           case 242: return launch_m1<BITS, 4, 4, 16, 8, true, 6>(p, stream);   // 64-column tiles, nontemporal, lookahead 6
           case 243: return launch_m1<BITS, 4, 4, 16, 8, true, 8>(p, stream);
+          case 260: return launch_helper<BITS, 4, 3, 16, 8, 0, 4>(p, stream);    // + one line-requesting helper wave per workgroup
+          case 261: return launch_helper<BITS, 4, 3, 16, 8, 0, 2>(p, stream);    // ... lookahead 2
+          case 262: return launch_helper<BITS, 4, 3, 16, 8, 0, 6>(p, stream);
+          case 263: return launch_helper<BITS, 4, 3, 16, 8, 2, 4>(p, stream);    // ... loads only
+          case 264: return launch_helper<BITS, 4, 4, 16, 8, 0, 4>(p, stream);    // 64-column tiles
+          case 250: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts);  // + prefetch workgroups for the next call's weights
+          case 255: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 0, 10);  // paced: wave w starts w * 640 clocks late
+          case 256: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 0, 20);  // ... w * 1280 clocks
+          case 257: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 0, 30);
+          case 258: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 1, 0, 20);  // paced, alone
+          case 251: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 1, 0);  // the prefetch workgroups alone (line touches, XCD stripes)
+          case 252: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 1);  // flat 16-byte reads instead of line touches
+          case 253: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 1, 1);  // ... alone
           case 231: return launch_la<BITS, 4, 3, 16, 8, 131072, 4>(p, stream);  // wait for a step's rows before issuing the next loads, lookahead 4
           case 232: return launch_la<BITS, 4, 3, 16, 8, 131072, 5>(p, stream);  // ... lookahead 5 (the same 5 rows outstanding at most)
           case 233: return launch_la<BITS, 4, 3, 16, 8, 131072, 6>(p, stream);
