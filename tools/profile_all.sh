@@ -17,6 +17,7 @@ run cfg4_shard8_w4_8192x3584_m1 --shape 8192,3584,4,128,1
 for b in 2 3 4 5 6 7 8; do run cfg3_w${b}_4096x4096_m1 --shape 4096,4096,$b,128,1; done
 for m in 1 4 16; do run cfg5_w3_4096x11008_m$m --shape 4096,11008,3,128,$m; done
 run w4_4096x11008_m16 --shape 4096,11008,4,128,16
+run w4_11008x4096_m1_measured_plan --shape 11008,4096,4,128,1
 run dequant_w4_4096x11008 --op dequant --shape 4096,11008,4,128,1
 run dequant_w4_4096x4096 --op dequant --shape 4096,4096,4,128,1
 run dequant_w3_4096x4096 --op dequant --shape 4096,4096,3,128,1
