@@ -136,3 +136,40 @@ def test_public_header_is_plain_c():
     for cmd in (["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], ["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_split_plan_occupancy_table(native_lib):
+    """The split-K planner prices a plan by how many of its workgroups fit on the chip at once, from the VGPR
+    counts of the split builds (kSplitVgprs in csrc/xbit_gemv_mfma.h).  The table must describe the library that
+    ships: read the counts back from the code objects embedded in the .so."""
+    import re
+
+    from xbitops_amd import _lib, codeobj
+
+    src = open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "xbit_gemv_mfma.h")).read()
+    body = re.search(r"kSplitVgprs\[7\]\[4\] = \{(.*?)\};", src, re.S).group(1)
+    table = [[int(x) for x in row.split(",")] for row in re.findall(r"\{([^{}]*)\}", body)]
+    assert len(table) == 7 and all(len(r) == 4 for r in table)
+    seen = {}
+    for name, r in codeobj.kernel_resources(_lib.LIB_PATH).items():
+        a = codeobj.gemv_template_args(name)
+        if a and a["split"] and a["nl"] == 16:
+            seen[(a["bits"], a["cpl"], a["mt"])] = r
+    for bits in range(2, 9):
+        for col, (cpl, mt) in enumerate(((4, 1), (4, 4), (2, 1), (2, 4))):
+            r = seen[(bits, cpl, mt)]
+            assert r["spill"] == 0, (bits, cpl, mt, r)
+            # the planner only needs the allocation class (512 // round_up(vgpr, 8) waves per SIMD) to be right
+            assert 512 // ((r["vgpr"] + 7) & ~7) == 512 // ((table[bits - 2][col] + 7) & ~7), (bits, cpl, mt, r["vgpr"], table[bits - 2][col])
+
+
+def test_no_kernel_in_the_library_spills(native_lib):
+    """Every kernel of the production library keeps its registers: the launchers do not compile the 16-wave
+    builds that would exceed 128 VGPRs (fits_16_waves in csrc/xbit_gemv_mfma.h) - measured up to 40 % slower
+    than 8 waves over two sweeps (profiles/r02/sweep_16_vs_8_waves.txt)."""
+    from xbitops_amd import _lib, codeobj
+
+    res = codeobj.kernel_resources(_lib.LIB_PATH)
+    assert len(res) > 100
+    bad = {n: r for n, r in res.items() if r["spill"] or r["scratch"]}
+    assert not bad, bad

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Print VGPR/SGPR/LDS/scratch per kernel from the .s files left by `python -m xbitops_amd.build --asm`."""
-import glob
+"""VGPR / SGPR / spills / scratch / LDS of every kernel in the built library (read from the code objects
+embedded in the .so: no --asm build needed).
+    python tools/kernel_resources.py [substring of the demangled name] [--tuning]
+"""
 import os
 import re
 import subprocess
 import sys
 
-OBJ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "xbitops_amd", "csrc", "_obj")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from xbitops_amd import _lib, codeobj  # noqa: E402
 
 
 def demangle(names):
@@ -17,20 +21,17 @@ def demangle(names):
         return names
 
 
-def main(pattern=""):
-    for f in sorted(glob.glob(os.path.join(OBJ, "*gfx950.s"))):
-        s = open(f).read()
-        rows = []
-        for b in s.split("  - .agpr_count:")[1:]:
-            g = lambda key: re.search(r"\." + key + r":\s+(\S+)", b).group(1)
-            rows.append((g("name"), g("vgpr_count"), g("sgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"),
-                         g("group_segment_fixed_size")))
-        names = demangle([r[0] for r in rows])
-        for r, n in zip(rows, names):
-            n = re.sub(r"^void ", "", n).split("(")[0]
-            if pattern in n:
-                print("%-80s vgpr=%3s sgpr=%3s spill=%s scratch=%s lds=%s" % (n[:80], r[1], r[2], r[3], r[4], r[5]))
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    pattern = args[0] if args else ""
+    res = codeobj.kernel_resources(_lib.TUNING_LIB_PATH if "--tuning" in sys.argv else _lib.LIB_PATH)
+    names = sorted(res)
+    for mangled, n in zip(names, demangle(names)):
+        n = re.sub(r"^void ", "", n).split("(")[0]
+        if pattern in n:
+            r = res[mangled]
+            print("%-84s vgpr=%3d sgpr=%3d spill=%d scratch=%d lds=%d" % (n[:84], r["vgpr"], r["sgpr"], r["spill"], r["scratch"], r["lds"]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "")
+    main()

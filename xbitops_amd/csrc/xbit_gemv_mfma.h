@@ -104,7 +104,14 @@ struct RowLoad {
 //          unpack/dequant/MFMA (loaded words are xor-folded), 3 = both (all three: wrong results);
 //          4 = correct results, always the spliced (pre-subnormal) unpack, for A/B timing;
 //          16 = correct results (M = 1), multiply-accumulate on the VALU (v_dot2_f32_f16 + shuffles) instead of the MFMA;
-//          8 = correct results plus per-wave s_memrealtime stamps written to p.trace
+//          8 = correct results plus per-wave s_memrealtime stamps written to p.trace;
+//          32 / 64 / 128 = no activation loads / no scale + zero loads / no cross-wave reduction; 256 / 512 = sc1 / sc0 on
+//          the weight loads; 1024 = first weight rows ahead of the small operands; 2048 / 4096 = addresses of a
+//          tile-contiguous layout / with a (scale | -z*s) row per batch (wrong results); 8192 / 16384 = activation
+//          slice of an 8-16 row pass staged in 4 / 2 parts; 32768 / 65536 = other forms of the reduction reads;
+//          131072 = wait for a step's rows before issuing the next; 262144 = extra workgroups touch the next call's
+//          weights; 524288 = a line-requesting helper wave per workgroup.  All of them: XBIT_TUNING builds only,
+//          each with its measurement under profiles/ (DESIGN.md section 4).
 //   LA   load lookahead in row loads (0 = issue the whole batch up front).  A wave issues in order,
 //        and the CU's memory pipeline back-pressures: a wave that queues all its loads first sits at
 //        the last load instruction until the queue drains and only then starts on data that came
@@ -751,6 +758,20 @@ constexpr TunedPlan kTunedPlans4[] = {
     {13824, 2560, 2, 6},  // ... its 2-way column shard: 7.20 against 8.00
 };
 
+// Waves of a split-K workgroup that fit on one CU: 4 SIMDs x (512 VGPRs / the build's allocation).  The wide-word
+// unpackers are register-hungry (7-bit, 64-column tiles: 170 VGPRs = two waves per SIMD), and a plan whose workgroups
+// do not all fit on the chip at once runs in rounds: 5-bit 11008x4096 took 14.6 us with nine K ranges of 5-wave
+// workgroups (two per CU, 576 of them: two rounds) and 9.3 with eleven of 4 waves (three per CU: one round).
+// VGPR counts of the SPLIT builds (tools/kernel_resources.py; rows: bits 2..8; columns: 64-column tiles at 1 / 4 rows,
+// 32-column tiles at 1 / 4 rows); tests/test_capi_and_host.py::test_split_plan_occupancy_table checks them against the library.
+constexpr uint16_t kSplitVgprs[7][4] = {{122, 124, 76, 80}, {145, 151, 89, 92}, {124, 134, 78, 84}, {158, 160, 92, 92},
+                                        {144, 144, 84, 84}, {170, 172, 100, 100}, {132, 132, 78, 82}};
+inline uint32_t split_waves_per_cu(int bits, int cpl, uint32_t m) {
+  if (bits < 2 || bits > 8) return 16u;
+  const uint32_t v = kSplitVgprs[bits - 2][(cpl == 4 ? 0 : 2) + (m > 1 ? 1 : 0)];
+  return 4u * (512u / ((v + 7u) & ~7u));
+}
+
 inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int bits = 0) {
   SplitPlan plan;
   if (p.m > 4 || forced_splits == 1) return plan;
@@ -780,7 +801,9 @@ inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int 
       if (bps < 16u) break;
       const uint32_t waves = sweep_waves(bps, 4, 8), sweeps = (bps + 4u * waves - 1) / (4u * waves), wgs = tiles * sp;
       const double fill = wgs < 256u ? wgs / 256.0 : 1.0;
-      const double score = (double)bps / (4.0 * waves * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85);
+      const uint32_t per_cu = split_waves_per_cu(bits, cpl, p.m) / waves;  // workgroups resident per CU
+      const uint32_t rounds = (wgs + 256u * (per_cu ? per_cu : 1u) - 1) / (256u * (per_cu ? per_cu : 1u));
+      const double score = (double)bps / (4.0 * waves * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85) / rounds;
       if (score > best + 1e-9) {
         best = score;
         plan.cpl = cpl;
@@ -858,18 +881,38 @@ int launch_rows16_ablate(GemvParams p, hipStream_t stream) {
 // Workgroup size: up to 16 waves when there is at most one workgroup per CU (<= 240 tiles), up to 8
 // otherwise (several 8-wave workgroups per CU sweeping K measured better: 8192x28672 26.2 -> 25.3 us,
 // 8192x8192 9.8 -> 9.2); within that cap, as many waves as fill whole sweeps (sweep_waves).
+// A 16-wave workgroup leaves each wave 128 VGPRs.  The builds that do not fit in that (they would spill: 3/5/6/7-bit
+// with 64-column tiles, 7-bit with 48, and the 4-row passes of 4- and 8-bit with 64) are not compiled; those shapes
+// run 8 waves over two sweeps - 7-bit 4096x11008: 9.8 us against 11.8 with the spilling 16-wave build
+// (profiles/r02/sweep_wide_word_bits.txt).  tests/test_capi_and_host.py checks that nothing in the library spills.
+template <int BITS, int CPL, int NL, int MT>
+constexpr bool fits_16_waves() {
+  if (XBIT_TUNING) return true;  // measurement builds keep every build (variant 120 caps the default path at 8 waves, 121 does not)
+  if (NL != 16) return true;
+  if (CPL == 4) return MT == 1 && (BITS == 2 || BITS == 4 || BITS == 8);
+  if (CPL == 3) return BITS != 7;
+  return true;
+}
+
 template <int BITS, int UB, int CPL, int NL, bool NT, int LA = lookahead_for<BITS>()>
-int launch_rows(const GemvParams& p, hipStream_t stream) {
+int launch_rows(const GemvParams& p, hipStream_t stream, uint32_t wave_cap = 16u) {
   constexpr uint32_t LK = 64 / NL, CN = NL * CPL;
   const uint32_t batches = ((p.k + 31) / 32 + UB - 1) / UB, tiles = (p.n + CN - 1) / CN;
-  if (p.m <= 4) {
-    const uint32_t waves = sweep_waves(batches, LK, tiles <= 240u ? 16u : 8u);
-    if (waves <= 8u) {
-      if (p.m == 1) return launch_one<BITS, UB, CPL, NL, 8, 1, NT, LA>(p, stream, waves);
-      return launch_one<BITS, UB, CPL, NL, 8, 4, NT, LA>(p, stream, waves);
+  if (p.m == 1) {
+    constexpr bool fit = fits_16_waves<BITS, CPL, NL, 1>();
+    const uint32_t waves = sweep_waves(batches, LK, (fit && tiles <= 240u && wave_cap >= 16u) ? 16u : 8u);
+    if constexpr (fit) {
+      if (waves > 8u) return launch_one<BITS, UB, CPL, NL, 16, 1, NT, LA>(p, stream, waves);
     }
-    if (p.m == 1) return launch_one<BITS, UB, CPL, NL, 16, 1, NT, LA>(p, stream, waves);
-    return launch_one<BITS, UB, CPL, NL, 16, 4, NT, LA>(p, stream, waves);
+    return launch_one<BITS, UB, CPL, NL, 8, 1, NT, LA>(p, stream, waves);
+  }
+  if (p.m <= 4) {
+    constexpr bool fit = fits_16_waves<BITS, CPL, NL, 4>();
+    const uint32_t waves = sweep_waves(batches, LK, (fit && tiles <= 240u && wave_cap >= 16u) ? 16u : 8u);
+    if constexpr (fit) {
+      if (waves > 8u) return launch_one<BITS, UB, CPL, NL, 16, 4, NT, LA>(p, stream, waves);
+    }
+    return launch_one<BITS, UB, CPL, NL, 8, 4, NT, LA>(p, stream, waves);
   }
   // 8-16 rows: the staged activation tile is 8-16x larger (139 KB of LDS at UB = 4, 8 waves, 16 rows).
   // Measured on 4096x11008 w4 M=16: 8 waves 9.0-9.3 us, 4 waves 11.0 us.
@@ -899,11 +942,11 @@ inline int pick_cpl(uint32_t n) {
 }
 
 template <int BITS, int UB, bool NT = false>
-int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl) {
+int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl, uint32_t wave_cap = 16u) {
   switch (cpl) {
-    case 4: return launch_rows<BITS, UB, 4, 16, NT>(p, stream);
-    case 3: return launch_rows<BITS, UB, 3, 16, NT>(p, stream);
-    default: return launch_rows<BITS, UB, 2, 16, NT>(p, stream);
+    case 4: return launch_rows<BITS, UB, 4, 16, NT>(p, stream, wave_cap);
+    case 3: return launch_rows<BITS, UB, 3, 16, NT>(p, stream, wave_cap);
+    default: return launch_rows<BITS, UB, 2, 16, NT>(p, stream, wave_cap);
   }
 }
 
@@ -922,10 +965,22 @@ int launch_multi_mt(GemvMultiParams p, hipStream_t stream, uint32_t waves) {
   return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, MT, false, true, 0, lookahead_for<BITS>(), false, true>, grid, block, stream, p);
 }
 
-template <int BITS, int UB, int CPL, int NW>
-int launch_multi_one(const GemvMultiParams& p, hipStream_t stream, uint32_t waves) {
-  if (p.m == 1) return launch_multi_mt<BITS, UB, CPL, NW, 1>(p, stream, waves);
-  return launch_multi_mt<BITS, UB, CPL, NW, 4>(p, stream, waves);
+template <int BITS, int UB, int CPL>
+int launch_multi_one(const GemvMultiParams& p, hipStream_t stream, uint32_t batches, uint32_t tiles) {
+  if (p.m == 1) {
+    constexpr bool fit = fits_16_waves<BITS, CPL, 16, 1>();
+    const uint32_t waves = sweep_waves(batches, 4, (fit && tiles <= 240u) ? 16u : 8u);
+    if constexpr (fit) {
+      if (waves > 8u) return launch_multi_mt<BITS, UB, CPL, 16, 1>(p, stream, waves);
+    }
+    return launch_multi_mt<BITS, UB, CPL, 8, 1>(p, stream, waves);
+  }
+  constexpr bool fit = fits_16_waves<BITS, CPL, 16, 4>();
+  const uint32_t waves = sweep_waves(batches, 4, (fit && tiles <= 240u) ? 16u : 8u);
+  if constexpr (fit) {
+    if (waves > 8u) return launch_multi_mt<BITS, UB, CPL, 16, 4>(p, stream, waves);
+  }
+  return launch_multi_mt<BITS, UB, CPL, 8, 4>(p, stream, waves);
 }
 
 template <int BITS>
@@ -938,15 +993,9 @@ int launch_multi_bits(const GemvMultiParams& p, hipStream_t stream) {
   uint32_t tiles = 0;
   for (uint32_t j = 0; j < p.multi_count; ++j) tiles += (p.multi_n[j] + 16u * cpl - 1) / (16u * cpl);
   const uint32_t batches = ((p.k + 31) / 32 + UBMAX - 1) / UBMAX;
-  const uint32_t waves = sweep_waves(batches, 4, tiles <= 240u ? 16u : 8u);
-  if (waves <= 8u) {
-    if (cpl == 4) return launch_multi_one<BITS, UBMAX, 4, 8>(p, stream, waves);
-    if (cpl == 3) return launch_multi_one<BITS, UBMAX, 3, 8>(p, stream, waves);
-    return launch_multi_one<BITS, UBMAX, 2, 8>(p, stream, waves);
-  }
-  if (cpl == 4) return launch_multi_one<BITS, UBMAX, 4, 16>(p, stream, waves);
-  if (cpl == 3) return launch_multi_one<BITS, UBMAX, 3, 16>(p, stream, waves);
-  return launch_multi_one<BITS, UBMAX, 2, 16>(p, stream, waves);
+  if (cpl == 4) return launch_multi_one<BITS, UBMAX, 4>(p, stream, batches, tiles);
+  if (cpl == 3) return launch_multi_one<BITS, UBMAX, 3>(p, stream, batches, tiles);
+  return launch_multi_one<BITS, UBMAX, 2>(p, stream, batches, tiles);
 }
 
 template <int BITS>
@@ -960,6 +1009,13 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     cpl = variant - 110;
     variant = -1;
   }
+  uint32_t wave_cap = 16u;
+  if (variant == 120 || variant == 121) {  // sweep hooks, any M: the default path with at most 8 / 16 waves per workgroup
+    wave_cap = variant == 120 ? 8u : 16u;
+    variant = -1;
+  }
+#else
+  constexpr uint32_t wave_cap = 16u;
 #endif
   if (p.groupsize % (32u * UBMAX) == 0) {
 #if XBIT_TUNING
@@ -1157,7 +1213,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     // stay cached anyway and stream ~9 % faster nontemporal (8192x28672: 25.8 -> 23.4 us); long
     // narrow ones (28672x8192) show no difference.  (profiles/r01/sweep_nt_large_shapes.txt)
     if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) return launch_cpl<BITS, UBMAX, true>(p, stream, cpl);
-    return launch_cpl<BITS, UBMAX>(p, stream, cpl);
+    return launch_cpl<BITS, UBMAX>(p, stream, cpl, wave_cap);
   }
   if constexpr (UBMAX > 2) {
     if (p.groupsize % 64u == 0) return launch_cpl<BITS, 2>(p, stream, cpl);
