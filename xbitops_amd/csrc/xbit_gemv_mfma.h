@@ -529,7 +529,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
             constexpr int e = decltype(e_c)::value;
             constexpr int pr = 4 * oct + e;
             uint32_t Q[CPL];
-            if constexpr (FAST) {
+            if constexpr (ABLATE & 1048576) {
+              // measurement (wrong results): the instruction mix of an integer-domain multiply - one v_and_or_b32 per
+              // pair (1024 + q * 2^e straight into the MFMA), one shift per word, no packed FMA
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) braw[c][e] = Unpack<BITS>::template pair<pr>(wc[c], uk);
+            } else if constexpr (FAST) {
 #pragma unroll
               for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template sub_pair<pr>(wc[c], sub_mask);
 #pragma unroll
@@ -1105,6 +1110,11 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 241: return launch_m1<BITS, 4, 4, 32, 8, true, 8>(p, stream);
           case 242: return launch_m1<BITS, 4, 4, 16, 8, true, 6>(p, stream);   // 64-column tiles, nontemporal, lookahead 6
           case 243: return launch_m1<BITS, 4, 4, 16, 8, true, 8>(p, stream);
+          case 270: return launch_la<BITS, 4, 3, 16, 8, 1048576, 4>(p, stream);   // integer-domain instruction mix (wrong results), 48-column tiles
+          case 271: return launch_la<BITS, 4, 4, 16, 8, 1048576, 4>(p, stream);   // ... 64-column tiles, 8 waves
+          case 272: return launch_la<BITS, 4, 4, 16, 8, 0, 4>(p, stream);         // reference for 271: the same launch, exact arithmetic
+          case 273: return launch_la<BITS, 4, 4, 32, 16, 1048576, 4>(p, stream);  // 128-column tiles, 16 waves (the 8192x28672 shape; plain loads)
+          case 274: return launch_la<BITS, 4, 4, 32, 16, 0, 4>(p, stream);        // reference for 273
           case 260: return launch_helper<BITS, 4, 3, 16, 8, 0, 4>(p, stream);    // + one line-requesting helper wave per workgroup
           case 261: return launch_helper<BITS, 4, 3, 16, 8, 0, 2>(p, stream);    // ... lookahead 2
           case 262: return launch_helper<BITS, 4, 3, 16, 8, 0, 6>(p, stream);
