@@ -1019,8 +1019,15 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     wave_cap = variant == 120 ? 8u : 16u;
     variant = -1;
   }
+  bool force_nt = false, force_plain = false;
+  if (variant == 122 || variant == 123) {  // sweep hooks, any M: the default path with nontemporal / plain weight loads
+    force_nt = variant == 122;
+    force_plain = variant == 123;
+    variant = -1;
+  }
 #else
   constexpr uint32_t wave_cap = 16u;
+  constexpr bool force_nt = false, force_plain = false;
 #endif
   if (p.groupsize % (32u * UBMAX) == 0) {
 #if XBIT_TUNING
@@ -1222,7 +1229,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     // faster when they are still in the Infinity Cache (4096x11008).  Very large, wide layers cannot
     // stay cached anyway and stream ~9 % faster nontemporal (8192x28672: 25.8 -> 23.4 us); long
     // narrow ones (28672x8192) show no difference.  (profiles/r01/sweep_nt_large_shapes.txt)
-    if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) return launch_cpl<BITS, UBMAX, true>(p, stream, cpl);
+    if (force_nt || (!force_plain && (uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u)) return launch_cpl<BITS, UBMAX, true>(p, stream, cpl, wave_cap);
     return launch_cpl<BITS, UBMAX>(p, stream, cpl, wave_cap);
   }
   if constexpr (UBMAX > 2) {
