@@ -448,25 +448,25 @@ def test_gemv_split_k_shapes(bits, cuda_device):
             assert torch.equal(XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1), ys[0])  # the plain operator takes the same path
 
 
-@pytest.mark.parametrize("k,n", [(11008, 4096), (13824, 2560)])
-def test_gemv_measured_plan_shapes(k, n, cuda_device):
-    """Down-projection shapes that take a measured split plan (kTunedPlans4 in xbit_gemv_mfma.h: 32-column tiles,
+@pytest.mark.parametrize("bits,k,n", [(4, 11008, 4096), (4, 13824, 2560), (3, 13824, 2560), (2, 11008, 4096)])
+def test_gemv_measured_plan_shapes(bits, k, n, cuda_device):
+    """Down-projection shapes that take a measured split plan (kTunedPlans in xbit_gemv_mfma.h: 32-column tiles,
     six K ranges, 4-5-wave workgroups) instead of the scored one: full size against the oracle, bit-stable across
     launches, and equal up to summation order to the unsplit launch and to a forced other plan."""
     import XbitOps
     from xbitops_amd import ops
 
-    p = synth.make_problem(k, n, 4, 128, m=1, seed=k + n)
-    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+    p = synth.make_problem(k, n, bits, 128, m=1, seed=k + n + bits)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, k, 1, oracle.RNE)
     a, qw, sc, qz = to_dev(p, cuda_device)
-    ys = [XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1) for _ in range(3)]
+    ys = [XbitOps.gemv(a, qw, sc, qz, 128, bits, k, 1) for _ in range(3)]
     torch.cuda.synchronize()
     for y in ys:
-        assert_gemv_close(y.cpu().numpy(), y_ref, "measured plan k=%d n=%d" % (k, n))
+        assert_gemv_close(y.cpu().numpy(), y_ref, "measured plan bits=%d k=%d n=%d" % (bits, k, n))
         assert torch.equal(y, ys[0])
     for forced in (1, 3):
-        y = ops.gemv_ex(a, qw, sc, qz, 128, 4, k, 1, split_k=forced)
-        assert_gemv_close(y.cpu().numpy(), y_ref, "split_k=%d k=%d n=%d" % (forced, k, n))
+        y = ops.gemv_ex(a, qw, sc, qz, 128, bits, k, 1, split_k=forced)
+        assert_gemv_close(y.cpu().numpy(), y_ref, "split_k=%d bits=%d k=%d n=%d" % (forced, bits, k, n))
 
 
 def test_split_k_with_caller_workspace(cuda_device):

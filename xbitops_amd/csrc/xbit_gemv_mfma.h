@@ -748,19 +748,27 @@ struct SplitPlan {
   int cpl = 0;
   uint32_t splits = 0;
 };
-// Shapes where a measured plan beats the scored one by >= 5 % (4-bit, one row; profiles/r02/sweep_split_plans_fine.txt:
-// every split factor 2..12 x both tile widths on 14 small-N shapes - on the other 11 the score is within 2.6 % of
-// the best).  All three are down-projections whose K is not a power of two: six K ranges of 15-18 batches run as
-// 4-5-wave workgroups, three or more per CU, where the score would take wide tiles with 4-6 waves per CU.
+// Shapes where a measured plan beats the scored one by >= 5 % (one row, g128; profiles/r02/sweep_split_plans_fine.txt:
+// every split factor 2..12 x both tile widths on 14 small-N shapes, 4-bit - on the other 11 the score is within 2.6 %
+// of the best - and sweep_split_plans_2_3_bit.txt for the same three shapes at 2 and 3 bits).  All are down-projections
+// whose K is not a power of two: 32-column tiles x six to eight K ranges of 14-18 batches run as 4-5-wave workgroups,
+// three or more per CU, where the score would take wide tiles with 4-6 waves per CU.
 struct TunedPlan {
+  int bits;
   uint32_t k, n;
   int cpl;
   uint32_t splits;
 };
-constexpr TunedPlan kTunedPlans4[] = {
-    {11008, 4096, 2, 6},  // Llama-7B down_proj:       7.64 us against 8.28
-    {13824, 5120, 2, 6},  // Llama-13B down_proj:     10.52 against 11.12
-    {13824, 2560, 2, 6},  // ... its 2-way column shard: 7.20 against 8.00
+constexpr TunedPlan kTunedPlans[] = {
+    {4, 11008, 4096, 2, 6},  // Llama-7B down_proj:         7.64 us against 8.28
+    {4, 13824, 5120, 2, 6},  // Llama-13B down_proj:       10.52 against 11.12
+    {4, 13824, 2560, 2, 6},  // ... its 2-way column shard:  7.20 against 8.00
+    {3, 11008, 4096, 2, 6},  //  7.28 against 8.20
+    {3, 13824, 5120, 2, 8},  //  9.52 against 10.48 (six ranges of 5-wave workgroups: 10.9)
+    {3, 13824, 2560, 2, 8},  //  6.96 against 7.76
+    {2, 11008, 4096, 2, 6},  //  6.76 against 7.72
+    {2, 13824, 5120, 2, 7},  //  8.60 against 9.68
+    {2, 13824, 2560, 2, 7},  //  6.52 against 7.40
 };
 
 // Waves of a split-K workgroup that fit on one CU: 4 SIMDs x (512 VGPRs / the build's allocation).  The wide-word
@@ -780,9 +788,9 @@ inline uint32_t split_waves_per_cu(int bits, int cpl, uint32_t m) {
 inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int bits = 0) {
   SplitPlan plan;
   if (p.m > 4 || forced_splits == 1) return plan;
-  if (forced_splits == 0 && bits == 4 && p.m == 1 && p.groupsize == 128u) {
-    for (const TunedPlan& t : kTunedPlans4)
-      if (t.k == p.k && t.n == p.n) {
+  if (forced_splits == 0 && p.m == 1 && p.groupsize == 128u) {
+    for (const TunedPlan& t : kTunedPlans)
+      if (t.bits == bits && t.k == p.k && t.n == p.n) {
         plan.cpl = t.cpl;
         plan.splits = t.splits;
         return plan;
