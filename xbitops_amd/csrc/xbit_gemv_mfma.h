@@ -816,7 +816,11 @@ inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int 
       const double fill = wgs < 256u ? wgs / 256.0 : 1.0;
       const uint32_t per_cu = split_waves_per_cu(bits, cpl, p.m) / waves;  // workgroups resident per CU
       const uint32_t rounds = (wgs + 256u * (per_cu ? per_cu : 1u) - 1) / (256u * (per_cu ? per_cu : 1u));
-      const double score = (double)bps / (4.0 * waves * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85) / rounds;
+      // 5-wave workgroups put two waves on one of the four SIMDs; the builds with more vector work per byte than
+      // 4-bit at 4 k-blocks per lane run at that SIMD's pace (4-bit g64 11008x4096: 10.5-10.7 us with 5, 9 or 10 K
+      // ranges - all 5 waves - against 7.9-8.8 with 3, 6, 7, 8 or 11; 5-bit and 3-bit alike; sweep_group_sizes.txt)
+      const double simd = (waves == 5u && !(bits == 4 && ub == 4)) ? 0.75 : 1.0;
+      const double score = (double)bps / (4.0 * waves * sweeps) * __builtin_sqrt(fill) * (cpl == 4 ? 1.0 : 0.85) * simd / rounds;
       if (score > best + 1e-9) {
         best = score;
         plan.cpl = cpl;
@@ -1241,7 +1245,19 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     return launch_cpl<BITS, UBMAX>(p, stream, cpl, wave_cap);
   }
   if constexpr (UBMAX > 2) {
-    if (p.groupsize % 64u == 0) return launch_cpl<BITS, 2>(p, stream, cpl);
+    if (p.groupsize % 64u == 0) {
+      // group size 64 at 2-4 bits: 2 k-blocks per lane.  Few column tiles and long K split here too (4-bit 11008x4096
+      // g64: 10.5 us unsplit; profiles/r02/sweep_group_sizes.txt); the occupancy table is that of the 4-k-block builds,
+      // which hold a few registers more (conservative)
+      SplitPlan plan = (variant > 0) ? SplitPlan{} : plan_split(p, 2, opts.split, BITS);
+      if (plan.splits >= 2) {
+        const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
+        const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
+        GemvWorkspace ws;
+        if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, 2>(p, stream, plan, ws);
+      }
+      return launch_cpl<BITS, 2>(p, stream, cpl);
+    }
   }
   return launch_cpl<BITS, 1>(p, stream, cpl);
 }
