@@ -1,0 +1,154 @@
+"""The staged-operand one-row GEMV (xbitops_amd/csrc/xbit_gemv_dyn.h) against the oracle: every bit-width, every tile
+shape, every count of staging rounds, group sizes from one k-block up, edge tiles, the spliced-form fallback - through
+the production entry point (which picks the kernel for these shapes) and, tile shape by tile shape, through the tuning
+library's forced variants.  GPU only."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from xbitops_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(x):
+    return np.ascontiguousarray(x).view(np.uint16)
+
+
+def _close(y, y_ref, what):
+    yf, rf = y.astype(np.float64), y_ref.astype(np.float64)
+    err = np.abs(yf - rf)
+    assert (err <= 1e-3 * np.abs(rf) + 2.0 ** -14).all(), "%s: worst err %.3e" % (what, err.max())
+    ulp = np.abs(_bits(y).astype(np.int32) - _bits(y_ref).astype(np.int32))
+    same_sign = (_bits(y) >> 15) == (_bits(y_ref) >> 15)
+    # exact W, fp32 sum: the oracle's value up to the last bit, except where the sum cancels to ~0 and the fp32 accumulation
+    # noise (a few 1e-6 absolute for the 2-bit problems here, whose terms are largest) exceeds an fp16 ulp
+    assert (((ulp <= 1) & same_sign) | (err <= 3e-5)).all(), what
+
+
+def _run(lib, p, bias, dev, variant=-1):
+    a, qw, sc, qz = (torch.from_numpy(x).to(dev) for x in (p.act, p.qweight, p.scales, p.qzeros))
+    out = torch.full((1, p.n), float("nan"), dtype=torch.float16, device=dev)
+    st = lib.xbit_gemv_f16_ex(out.data_ptr(), a.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), p.bits, p.groupsize, 1, p.k, p.n, bias,
+                              torch.cuda.current_stream().cuda_stream, _lib.GemvOptions(variant=variant))
+    _lib.check(st, "xbit_gemv_f16_ex")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _ref(p, bias):
+    return oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, p.groupsize, p.bits, p.k, bias, oracle.RNE)
+
+
+# (k, n, groupsize): tiles of 32 / 48 / 64 / 16 columns by the launcher's rule, 2 / 4 / 8 staging rounds, edge tiles, long K
+SHAPES = [(4096, 11008, 128), (4096, 4096, 128), (4096, 8192, 128), (4096, 512, 128), (8192, 7168, 128), (11008, 5504, 128), (2048, 8200, 64),
+          (4096, 6150, 256), (1024, 8192, 64), (8192, 1536, 128), (256, 64, 64), (4096, 11008, 64)]
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_production_one_row_shapes_vs_oracle(bits, cuda_device):
+    lib = _lib.load()
+    for k, n, g in SHAPES:
+        p = synth.make_problem(k, n, bits, g, m=1, seed=bits * 977 + k + n)
+        _close(_run(lib, p, 1, cuda_device), _ref(p, 1), (bits, k, n, g))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+@pytest.mark.parametrize("variant", [301, 302, 303, 304, 311, 313])
+def test_forced_tile_shapes_equal_the_oracle_and_each_other(bits, variant, cuda_device):
+    """Tuning library: 16-column tiles (8 lanes), 32 / 48 / 64-column tiles, nontemporal and plain row loads."""
+    lib = _lib.load_tuning()
+    for k, n, g in [(4096, 1030, 128), (2048, 4096, 32 if bits != 2 else 64), (8192, 344, 128)]:
+        p = synth.make_problem(k, n, bits, g, m=1, seed=bits * 31 + variant)
+        y = _run(lib, p, 0, cuda_device, variant)
+        _close(y, _ref(p, 0), (bits, variant, k, n, g))
+        assert np.array_equal(_bits(y), _bits(_run(lib, p, 0, cuda_device, variant)))  # launch to launch: identical
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_large_scale_takes_the_spliced_form_with_the_same_w(bits, cuda_device):
+    """One scale too large for the subnormal form (and one infinite, one NaN in another tile) switch their workgroups to the
+    spliced form: the columns of unaffected scales still equal the oracle bit for bit, the affected ones as the oracle says."""
+    lib = _lib.load()
+    k, n, g = 4096, 2048, 128
+    p = synth.make_problem(k, n, bits, g, m=1, seed=bits + 500)
+    sc = p.scales.copy()
+    sc[3, 5] = np.float16(30.0)      # s * 2^(14 + bits) overflows fp16
+    sc[7, 700] = np.float16(np.inf)
+    sc[9, 1500] = np.float16(np.nan)
+    p2 = synth.Problem(k, n, bits, g, 1, p.qweight, sc, p.qzeros, p.act)
+    y, y_ref = _run(lib, p2, 1, cuda_device), _ref(p2, 1)
+    finite = np.isfinite(y_ref.astype(np.float32))
+    assert np.array_equal(np.isnan(y.astype(np.float32)), np.isnan(y_ref.astype(np.float32)))
+    _close(y[finite], y_ref[finite], bits)
+
+
+def test_dyn_kernel_is_what_serves_the_metric_shape(cuda_device):
+    """rocprof names the kernel; here: the forced variant (tuning library) and the production launch agree bit for bit on
+    the metric shape while the round-2 kernel (variant 399) differs in summation order somewhere."""
+    lib, tun = _lib.load(), _lib.load_tuning()
+    p = synth.make_problem(4096, 11008, 4, 128, m=1, seed=77)
+    y_prod, y_dyn, y_old = _run(lib, p, 1, cuda_device), _run(tun, p, 1, cuda_device, 300), _run(tun, p, 1, cuda_device, 399)
+    assert np.array_equal(_bits(y_prod), _bits(y_dyn))
+    _close(y_old, _ref(p, 1), "round-2 kernel")
+    assert not np.array_equal(_bits(y_old), _bits(y_dyn))
+
+
+# the reference harness's own ragged K (main.cc:21 forces MATRIX_K = 7167) and friends: any k, one row -> still the fast kernel
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_ragged_k_one_row(bits, cuda_device):
+    lib = _lib.load()
+    for k, n, g in [(7167, 4096, 128), (4097, 1024, 128), (1001, 520, 64), (63, 64, 64), (4100, 11008, 128)]:
+        p = synth.make_problem(k, n, bits, g, m=1, seed=bits * 7 + k)
+        _close(_run(lib, p, 1, cuda_device), _ref(p, 1), (bits, k, n, g))
+
+
+def _run_rows(lib, p, bias, dev):
+    a, qw, sc, qz = (torch.from_numpy(x).to(dev) for x in (p.act, p.qweight, p.scales, p.qzeros))
+    out = torch.full((p.m, p.n), float("nan"), dtype=torch.float16, device=dev)
+    st = lib.xbit_gemv_f16(out.data_ptr(), a.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), p.bits, p.groupsize, p.m, p.k, p.n, bias,
+                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "xbit_gemv_f16")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_column_kernel_shapes(bits, cuda_device):
+    """What no fast kernel takes - group sizes that are not a multiple of 32 (16, 48, 80, 1000: a group may begin anywhere
+    inside a k-block), ragged K with several rows, odd tile edges - runs the coalesced column kernel: exact W, fp32 sums."""
+    lib = _lib.load()
+    for k, n, g, m in [(4096, 1024, 48, 1), (2048, 130, 16, 1), (7167, 512, 80, 1), (1000, 66, 1000, 3), (333, 64, 17, 5), (7167, 1024, 128, 4), (96, 2, 16, 2)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m))
+
+
+def test_column_kernel_takes_misaligned_tensors(cuda_device):
+    """Tensors aligned to their element size only (views at odd element offsets): still served, still exact."""
+    lib = _lib.load()
+    k, n, bits, g = 1024, 256, 4, 128
+    p = synth.make_problem(k, n, bits, g, m=2, seed=5)
+    dev = cuda_device
+
+    def shifted(x, elems):  # the same values at an address that is `elems` elements past an aligned one
+        buf = torch.empty(x.numel() + elems + 64, dtype=x.dtype, device=dev)
+        view = buf[elems:elems + x.numel()].view(x.shape)
+        view.copy_(x)
+        return buf, view
+
+    keep = []
+    a = shifted(torch.from_numpy(p.act).to(dev), 1)       # 2-byte aligned
+    qw = shifted(torch.from_numpy(p.qweight).to(dev), 1)  # 4-byte aligned, not 16
+    sc = shifted(torch.from_numpy(p.scales).to(dev), 3)   # 2-byte aligned
+    qz = shifted(torch.from_numpy(p.qzeros).to(dev), 1)
+    keep += [a, qw, sc, qz]
+    out = torch.empty((2, n), dtype=torch.float16, device=dev)
+    st = lib.xbit_gemv_f16(out.data_ptr(), a[1].data_ptr(), qw[1].data_ptr(), sc[1].data_ptr(), qz[1].data_ptr(), bits, g, 2, k, n, 1,
+                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "xbit_gemv_f16")
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), "misaligned")

@@ -92,6 +92,43 @@ def test_dequant_vs_reference_fixture(path, cuda_device):
     assert np.array_equal(_bits(w), _bits(w_rne))  # bit-exact vs hardware-rounding oracle
 
 
+def reference_gemv_errors(y, y_ref):
+    """The reference harness's own acceptance rule for the fused GEMV (src/cu/gemv_w4a16.cu:406-407): an element is
+    an error iff (ref / v1 > 1.001 or v1 / ref > 1.001) and |ref - v1| > 4e-4.  Written so that NaN / Inf on one side
+    only counts as an error (the reference's comparison is false for NaN)."""
+    v1, ref = y.astype(np.float64).ravel(), y_ref.astype(np.float64).ravel()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = (np.abs(ref / v1) > 1.001) | (np.abs(v1 / ref) > 1.001)
+        far = np.abs(ref - v1) > 4e-4
+    broken = ~np.isfinite(v1) | ~np.isfinite(ref)
+    return int(((ratio & far) | (broken & (v1 != ref))).sum())
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+@pytest.mark.parametrize("m", [1, 4])
+def test_gemv_vs_reference_fixture_weights(path, m, cuda_device):
+    """The direct link: HIP GEMV against an fp32 matmul of the weights the REFERENCE SIMULATOR produced (fixture `w_ref`,
+    oracle/gen_golden.py), judged by the reference's own rule - no oracle code between the two.
+    The simulator rounds fp32 -> fp16 half-up (cpp_simulate.cc:43-59) where hardware (CUDA and this kernel alike) rounds to
+    nearest even, so 4-14 % of its W are one ulp high and a K = 200..384 sum over them is biased by up to ~1.2e-3
+    (measured on these fixtures with W rebuilt in hardware rounding).  The reference's rule therefore flags a few outputs
+    for ANY hardware kernel; what is asserted is that nothing lies outside that rounding band: every flagged output is
+    within 2e-3 absolute, at most 8 % of the outputs are flagged (worst fixture: 4.9 %), and the reference's own pass
+    criterion (`errors > 100000` fails, gemv_w4a16.cu:413) holds trivially."""
+    f = np.load(path)
+    k, n, bits, g, seed = (int(v) for v in f["meta"])
+    p = synth.make_problem(k, n, bits, g, m=m, seed=seed)
+    assert np.array_equal(p.qweight, f["qweight"]) and np.array_equal(_bits(p.scales), _bits(f["scales"]))
+    y = run_gemv(p, 0, cuda_device)
+    y_ref = p.act.astype(np.float32) @ f["w_ref"].astype(np.float32)  # fp32 accumulate over the simulator's fp16 W
+    flagged = reference_gemv_errors(y, y_ref)
+    err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+    assert np.isfinite(y.astype(np.float32)).all()
+    assert flagged <= 0.08 * y.size, (flagged, y.size)
+    assert err.max() <= 2e-3, err.max()
+    assert (err <= 1e-3 * np.abs(y_ref) + 2e-3).all()
+
+
 DQ_CASES = [
     # k, n, g, bias  — aligned, ragged K, group smaller than a k-block, generic-path shapes
     (256, 128, 128, 0), (256, 128, 128, 1), (4096, 256, 128, 1), (200, 64, 32, 0), (7167 // 7, 72, 64, 1),
@@ -277,12 +314,20 @@ def test_gemv_linearity_full_size(cuda_device):
     dev = cuda_device
     _a, qw, sc, qz = to_dev(p, dev)
     ys = []
-    for a in (a1, a2, (a1.astype(np.float32) + a2.astype(np.float32)).astype(np.float16), np.concatenate([a1, a2], 0)):
-        ys.append(XbitOps.gemv(torch.from_numpy(a).to(dev), qw, sc, qz, 128, 4, 4096, 1).float().cpu().numpy())
-    y1, y2, y12, yb = ys
-    scale = np.abs(y1) + np.abs(y2) + 1e-3
-    assert (np.abs(y12 - (y1 + y2)) <= 3e-3 * scale).all()
-    assert np.array_equal(yb[0:1], y1) and np.array_equal(yb[1:2], y2)  # batch rows independent and deterministic
+    for a in (a1, a2, (a1.astype(np.float32) + a2.astype(np.float32)).astype(np.float16), np.concatenate([a1, a2], 0), np.concatenate([a2, a1, a2, a1], 0), a1):
+        ys.append(XbitOps.gemv(torch.from_numpy(a).to(dev), qw, sc, qz, 128, 4, 4096, 1).cpu().numpy())
+    y1, y2, y12, yb, yq, y1_again = ys
+    scale = np.abs(y1.astype(np.float32)) + np.abs(y2.astype(np.float32)) + 1e-3
+    assert (np.abs(y12.astype(np.float32) - (y1.astype(np.float32) + y2.astype(np.float32))) <= 3e-3 * scale).all()
+    assert np.array_equal(_bits(y1), _bits(y1_again))  # deterministic from launch to launch
+    # batch rows are independent of their position and of their neighbours (bit for bit within the multi-row kernel) ...
+    assert np.array_equal(_bits(yb[0]), _bits(yq[1])) and np.array_equal(_bits(yb[1]), _bits(yq[0])) and np.array_equal(_bits(yq[0]), _bits(yq[2]))
+    # ... and equal to the one-row launch, which runs another kernel (xbit_gemv_dyn.h) with another summation order, up to
+    # the last bit of the fp16 result (both accumulate the same exact W in fp32; |y| >= 2^-6 so an ulp is meaningful)
+    for yrow, ysingle in ((yb[0], y1[0]), (yb[1], y2[0])):
+        big = np.abs(ysingle.astype(np.float32)) >= 2.0 ** -6
+        ulp = np.abs(_bits(yrow).astype(np.int32) - _bits(ysingle).astype(np.int32))
+        assert (ulp[big] <= 1).all() and (np.abs(yrow.astype(np.float32) - ysingle.astype(np.float32))[~big] <= 2.0 ** -16).all()
 
 
 def test_gemv_3d_input_and_bf16_scales(cuda_device):

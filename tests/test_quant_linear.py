@@ -112,3 +112,47 @@ def test_quant_linear_group(cuda_device):
             assert (y.float() - want.float()).abs().max() <= 1e-3 * want.float().abs().max() + 2.0 ** -14
     with pytest.raises(ValueError):
         QuantLinearGroup([layers[0], QuantLinear.from_float(torch.randn(512, 64) * 0.05, bits=4, groupsize=128).to(cuda_device)])
+
+
+def _act_order_layers():
+    from xbitops_amd import synth
+    from xbitops_amd.linear import QuantLinear
+
+    k, n, bits, g = 256, 64, 4, 64
+    p = synth.make_problem(k, n, bits, g, m=1, seed=3)
+    rng = np.random.default_rng(0)
+    gi = np.repeat(np.arange(k // g), g)
+    rng.shuffle(gi)
+    equal = QuantLinear.from_act_order(p.qweight, p.scales, p.qzeros, gi, bits, g, 1)  # rows sorted at load time: `perm`
+    gi2 = gi.copy()
+    gi2[:5] = 0
+    general = QuantLinear.from_act_order(p.qweight, p.scales, p.qzeros, gi2, bits, g, 1)  # unequal groups: `g_idx` kept
+    assert equal.perm is not None and equal.g_idx is None and general.g_idx is not None and general.perm is None
+    return (k, n, bits, g), equal, general
+
+
+def test_act_order_state_dict_round_trip():
+    """A fresh layer must come out of load_state_dict with the permutation / g_idx of the saved one (strict AND non-strict);
+    before, strict loading raised on the extra key and strict=False dropped it silently - wrong results afterwards."""
+    from xbitops_amd.linear import QuantLinear
+
+    (k, n, bits, g), equal, general = _act_order_layers()
+    for src, name in ((equal, "perm"), (general, "g_idx")):
+        sd = src.state_dict()
+        assert name in sd
+        for strict in (True, False):
+            dst = QuantLinear(k, n, bits, g, 1)
+            res = dst.load_state_dict(sd, strict=strict)
+            assert not res.missing_keys and not res.unexpected_keys
+            assert torch.equal(getattr(dst, name), getattr(src, name))
+            assert torch.equal(dst.qweight, src.qweight)
+            other = "g_idx" if name == "perm" else "perm"
+            assert getattr(dst, other) is None
+    # a plain checkpoint loaded into a layer that held a permutation drops it (the rows it described are gone)
+    equal.load_state_dict(QuantLinear(k, n, bits, g, 1).state_dict())
+    assert equal.perm is None and equal.g_idx is None
+    # a permutation of the wrong length is an error, not a silent mismatch
+    bad = dict(general.state_dict())
+    bad["g_idx"] = bad["g_idx"][:-1]
+    with pytest.raises(RuntimeError):
+        QuantLinear(k, n, bits, g, 1).load_state_dict(bad)

@@ -26,8 +26,9 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libxbitops_hip.so")
 TUNING_LIB = os.path.join(LIB_DIR, "libxbitops_hip_tuning.so")
 OBJ_TUNING = os.path.join(CSRC, "_obj_tuning")
-SOURCES = ["xbit_capi.hip", "xbit_dequant.hip", "xbit_gidx.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip"] + ["xbit_gemv_mfma_b%d.hip" % b for b in range(2, 9)]
-HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", "xbit_gemv_mfma.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
+SOURCES = (["xbit_capi.hip", "xbit_dequant.hip", "xbit_gidx.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip", "xbit_gemv_dyn.hip"] +
+           ["xbit_gemv_mfma_b%d.hip" % b for b in range(2, 9)] + ["xbit_gemv_dyn_b%d.hip" % b for b in range(2, 9)])
+HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", "xbit_gemv_mfma.h", "xbit_gemv_dyn.h", "xbit_harness_check.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
             "--offload-arch=" + ARCH]
@@ -50,10 +51,26 @@ def is_current(tuning: bool = False) -> bool:
     return os.path.exists(lib) and os.path.getmtime(lib) >= _newest_input()
 
 
-def _compile(src: str, keep_asm: bool, tuning: bool) -> str:
+def _object_is_current(obj: str) -> bool:
+    """True when `obj` is newer than its source and every header the compiler saw (the .d file written next to it)."""
+    dep = obj + ".d"
+    if not (os.path.exists(obj) and os.path.exists(dep)):
+        return False
+    t = os.path.getmtime(obj)
+    text = open(dep).read().replace("\\\n", " ")
+    files = text.split(":", 1)[1].split() if ":" in text else []
+    try:
+        return bool(files) and all(os.path.getmtime(f) <= t for f in files if f.startswith(os.path.dirname(HERE)))  # this repo's files; the toolchain's own headers do not change
+    except OSError:
+        return False
+
+
+def _compile(src: str, keep_asm: bool, tuning: bool, force: bool = False) -> str:
     objdir = OBJ_TUNING if tuning else OBJ
     obj = os.path.join(objdir, src.replace(".hip", ".o"))
-    cmd = [hipcc()] + CXXFLAGS + (["-DXBIT_TUNING=1"] if tuning else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if not force and not keep_asm and _object_is_current(obj):
+        return obj
+    cmd = [hipcc()] + CXXFLAGS + (["-DXBIT_TUNING=1"] if tuning else []) + ["-MD", "-MF", obj + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
     if keep_asm:
         cmd += ["-save-temps=obj"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=objdir)
@@ -68,13 +85,14 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False, tu
     """Compile every HIP source for gfx950 and link the shared library (the production one, or with
     ``tuning=True`` the measurement build).  Returns its path."""
     lib = TUNING_LIB if tuning else LIB
-    if not force and not keep_asm and is_current(tuning):
-        return lib
     objdir = OBJ_TUNING if tuning else OBJ
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
+    # every source goes through _compile, which recompiles only what is older than its own inputs (the .d files)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
-        objs = list(pool.map(lambda s: _compile(s, keep_asm, tuning), SOURCES))
+        objs = list(pool.map(lambda s: _compile(s, keep_asm, tuning, force), SOURCES))
+    if not force and os.path.exists(lib) and all(os.path.getmtime(o) <= os.path.getmtime(lib) for o in objs):
+        return lib
     cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib + ".tmp"] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -122,7 +140,7 @@ def build_harness(force: bool = False) -> str:
     harness (include/xbitops_harness.h) over the C ABI — and examples/harness_main, a host shaped like
     the reference's main.cc that calls it."""
     lib = build()
-    if force or _stale(HARNESS_LIB, HARNESS_SRC, lib, os.path.join(INCLUDE, "xbitops_harness.h")):
+    if force or _stale(HARNESS_LIB, HARNESS_SRC, lib, os.path.join(INCLUDE, "xbitops_harness.h"), os.path.join(CSRC, "xbit_harness_check.h")):
         _run([hipcc(), "-O2", "-w", "-fPIC", "-shared", "-fvisibility=hidden", "-x", "hip", "--offload-arch=" + ARCH, HARNESS_SRC, "-o", HARNESS_LIB,
               "-L", LIB_DIR, "-lxbitops_hip", "-Wl,-rpath,$ORIGIN"], HARNESS_SRC)
     if force or _stale(HARNESS_MAIN_BIN, HARNESS_MAIN_SRC, HARNESS_LIB):

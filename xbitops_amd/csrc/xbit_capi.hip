@@ -21,15 +21,41 @@ int launch_raw(const void* kernel, dim3 grid, dim3 block, hipStream_t stream, vo
   return launch_raw_dynamic(kernel, grid, block, 0, stream, args);
 }
 
+namespace {
+// Kernels that may ask for more than the 64 KB of LDS a launch gets by default are raised ONCE per (kernel, device) to
+// the chip's whole 160 KB, never per call to the call's own size: two host threads launching the same kernel with
+// different sizes would otherwise lower each other's limit between the attribute call and the launch.
+constexpr int kMaxLds = 160 << 10;
+std::mutex g_lds_mutex;
+std::map<std::pair<const void*, int>, bool> g_lds_raised;
+int raise_lds_limit(const void* kernel) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)hipErrorInvalidDevice;
+  }
+  std::lock_guard<std::mutex> lock(g_lds_mutex);
+  bool& done = g_lds_raised[std::make_pair(kernel, dev)];
+  if (done) return XBIT_OK;
+  hipFuncAttributes fa;
+  hipError_t err = hipFuncGetAttributes(&fa, kernel);  // the limit covers dynamic LDS only: leave room for the kernel's static part
+  if (err == hipSuccess) err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - (int)fa.sharedSizeBytes);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)err;
+  }
+  done = true;
+  return XBIT_OK;
+}
+}  // namespace
+
 int launch_raw_dynamic(const void* kernel, dim3 grid, dim3 block, size_t dynamic_lds, hipStream_t stream, void** args) {
   ProfileState& ps = profile_state();
   hipError_t err = hipSuccess;
-  if (dynamic_lds > (size_t)(32 << 10)) {  // statics + dynamic may pass the 64 KB default: allow the chip's 160 KB
-    err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_lds);
-    if (err != hipSuccess) {
-      (void)hipGetLastError();
-      return (int)err;
-    }
+  if (dynamic_lds > (size_t)kMaxLds) return XBIT_ERR_SHAPE;
+  if (dynamic_lds > (size_t)(32 << 10)) {  // statics + dynamic may pass the 64 KB default
+    const int st = raise_lds_limit(kernel);
+    if (st != XBIT_OK) return st;
   }
   if (ps.enabled) {
     err = hipExtLaunchKernel(kernel, grid, block, args, dynamic_lds, stream, ps.start, ps.stop, 0);

@@ -234,29 +234,75 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1,
 
 #endif  // XBIT_TUNING
 
-// Fully general fallback: any n (even), any groupsize, any k.  One workgroup per output element
-// column-block of 1; slow (re-reads scales per element) but exact.  Used only for shapes the tiled
-// kernel does not take (n % 4 != 0 or groupsize % 32 != 0).
-__global__ void __launch_bounds__(256) gemv_generic_kernel(const GemvParams p, int bits) {
-  __shared__ float s_part[256];
-  const uint32_t col = blockIdx.x, row = blockIdx.y;
-  float acc = 0.f;
-  for (uint32_t k = threadIdx.x; k < p.k; k += 256) {
-    const uint32_t g = k / p.groupsize;
-    const _Float16 s = as_h(p.scales[(size_t)g * p.n + col]);
-    const uint32_t z = stream_field(p.qzeros + (size_t)g * p.zw, 1, col, bits, p.zw) + p.bias;
-    const uint32_t q = stream_field(p.qweight + col, p.n, k, bits, p.kw);
-    const _Float16 nzs = neg_zero_times_scale(z, s);
-    const _Float16 w = __builtin_elementwise_fma((_Float16)(float)(int)q, s, nzs);
-    acc += (float)as_h(p.a[(size_t)row * p.k + k]) * (float)w;
+// Fully general fallback: any n, any group size (16, 48, ... - a group may begin anywhere inside a k-block), any k, M rows,
+// tensors aligned to their element size only.  A workgroup owns 64 adjacent columns (one per lane: every packed row is
+// one coalesced 256-byte read per wave) over all of K; its four waves take every fourth k-block; a lane unpacks its
+// column's 32 fields with compile-time shifts, looks the (scale, zero-point) pair up again whenever the group changes
+// (wave-uniform), rebuilds W exactly as the fast kernels do and accumulates in fp32; the activations of a k-block sit one
+// per lane and are broadcast with v_readlane.  Replaces the round-1 kernel that gave every OUTPUT ELEMENT a workgroup
+// and gathered each field with its own 4-byte read (profiles/r03/sweep_ragged_shapes.txt).
+template <int BITS, int MT>
+__global__ void __launch_bounds__(256) gemv_columns_kernel(const GemvParams p) {
+  __shared__ float s_part[4][MT][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t col = blockIdx.x * 64u + (uint32_t)lane, m0 = blockIdx.y * (uint32_t)MT;
+  const bool col_ok = col < p.n;
+  const uint32_t kblocks = (p.k + 31u) / 32u;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  for (uint32_t kb = (uint32_t)wv; kb < kblocks; kb += 4u) {
+    uint32_t w[BITS];
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) {
+      const uint32_t row = kb * (uint32_t)BITS + (uint32_t)i;
+      w[i] = (col_ok && row < p.kw) ? p.qweight[(size_t)row * p.n + col] : 0u;
+    }
+    // activation k = 32 * kb + (lane & 31) of each row, as fp32 bits (both halves of the wave hold the same 32 values)
+    uint32_t av[MT];
+    const uint32_t k_l = kb * 32u + (uint32_t)(lane & 31);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bool on = k_l < p.k && m0 + (uint32_t)m < p.m;
+      av[m] = on ? __builtin_bit_cast(uint32_t, (float)as_h(p.a[(size_t)(m0 + (uint32_t)m) * p.k + k_l])) : 0u;
+    }
+    uint32_t g = (kb * 32u) / p.groupsize, rem = (kb * 32u) % p.groupsize;  // wave-uniform
+    _Float16 s = (_Float16)0.f, nzs = (_Float16)0.f;
+    bool fresh = true;
+    static_for<32>([&](auto idx_c) {
+      constexpr int idx = decltype(idx_c)::value;
+      if (fresh) {  // first field of the k-block, or the group changed: wave-uniform
+        s = (col_ok && g < p.groups) ? as_h(p.scales[(size_t)g * p.n + col]) : (_Float16)0.f;
+        const uint32_t z = ((col_ok && g < p.groups) ? stream_field(p.qzeros + (size_t)g * p.zw, 1, col, BITS, p.zw) : 0u) + p.bias;
+        nzs = neg_zero_times_scale(z, s);
+      }
+      const uint32_t q = field<BITS>(w, idx);
+      const float wf = (float)__builtin_elementwise_fma((_Float16)(float)(int)q, s, nzs);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] += __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_readlane((int)av[m], idx)) * wf;
+      ++rem;
+      fresh = rem == p.groupsize;
+      if (fresh) {
+        rem = 0;
+        ++g;
+      }
+    });
   }
-  s_part[threadIdx.x] = acc;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) s_part[wv][m][lane] = acc[m];
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
-    __syncthreads();
+  if (tid < 64 * MT) {
+    const int m = tid >> 6;
+    const float sum = s_part[0][m][lane] + s_part[1][m][lane] + s_part[2][m][lane] + s_part[3][m][lane];
+    if (col_ok && m0 + (uint32_t)m < p.m) p.out[(size_t)(m0 + (uint32_t)m) * p.n + col] = as_u16((_Float16)sum);
   }
-  if (threadIdx.x == 0) p.out[(size_t)row * p.n + col] = as_u16((_Float16)s_part[0]);
+}
+
+template <int BITS>
+int launch_columns(const GemvParams& p, hipStream_t stream) {
+  if (p.m == 1u) return launch(gemv_columns_kernel<BITS, 1>, dim3((p.n + 63u) / 64u, 1), dim3(256), stream, p);
+  return launch(gemv_columns_kernel<BITS, 4>, dim3((p.n + 63u) / 64u, (p.m + 3u) / 4u), dim3(256), stream, p);
 }
 
 #if XBIT_TUNING
@@ -327,10 +373,24 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
   if (dot2_ok && opts.variant >= 1 && opts.variant < 10) return launch_bits<4>(p, stream, opts.variant);
 #endif
   if (mfma_ok) return launch_gemv_mfma(p, bits, stream, opts);
-  // everything else: exact but slow
-  if (p.m > 65535u) return XBIT_ERR_SHAPE;
-  dim3 grid(p.n, p.m), block(256);
-  return launch(gemv_generic_kernel, grid, block, stream, p, bits);
+  // One row of any length k (the reference harness's own K = 7167, main.cc:21): the staged-operand kernel masks the tail
+  // of the activation vector itself, so only group sizes that are not a multiple of 32 (or tensors that are not even
+  // 4-byte aligned, or 2 GiB and more) go on to the column kernel below.
+  if (p.m == 1u && small && p.groupsize % 32u == 0 && !(XBIT_TUNING && opts.variant == 399)) {
+    const int st = launch_gemv_dyn(p, bits, stream, pick_cpl(p.n), 16, true, false, nullptr);
+    if (st != kGemvDynNotEligible) return st;
+  }
+  // everything else: exact, coalesced, a few times slower than the fast kernels
+  if (p.m > 65535u * 4u) return XBIT_ERR_SHAPE;
+  switch (bits) {
+    case 2: return launch_columns<2>(p, stream);
+    case 3: return launch_columns<3>(p, stream);
+    case 4: return launch_columns<4>(p, stream);
+    case 5: return launch_columns<5>(p, stream);
+    case 6: return launch_columns<6>(p, stream);
+    case 7: return launch_columns<7>(p, stream);
+    default: return launch_columns<8>(p, stream);
+  }
 }
 
 }  // namespace xbit

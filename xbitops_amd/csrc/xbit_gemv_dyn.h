@@ -1,0 +1,520 @@
+// xbit_gemv_dyn.h — A16Wx GEMV for ONE activation row (decode), gfx950, bits 2..8: whole-K column tiles, small
+// operands staged once per workgroup by HALF of its waves while the other half already streams weights.
+//
+// Same packed layout, same arithmetic and the same lane map as xbit_gemv_mfma.h (NL lanes x CPL adjacent columns,
+// 64 / NL k-slots per wave, a lane owns whole k-blocks, W rebuilt bit for bit in packed fp16, multiply-accumulate on
+// v_mfma_f32_16x16x32_f16, row loads woven into the compute stream a few rows ahead).  What differs is the opening of
+// the kernel, which is where a launch of this size loses most (profiles/r03/):
+//
+//   * A CU's vector-memory pipeline accepts one wave-level load every ~35-40 clocks whatever its width.  In
+//     xbit_gemv_mfma.h every wave opens with three small loads (activation slice, scales, zero-points) and five row
+//     loads: 64 instructions per CU, ~1 us before the last wave's first row is even requested
+//     (trace_detail_v63.txt: waves 4-7 trail waves 0-3 by 0.5 us at "loads issued" and by 0.9 us at the end).
+//   * Here K is cut into units of (64 / NL) * UB k-blocks that ANY wave can work on, because the small operands are
+//     staged ONCE per workgroup: the whole activation vector (pair order, 2 B per k) and one (scale, -zero*scale)
+//     entry per group and column go to LDS.  STW of the NW waves do that staging (the same three small loads per
+//     thread, SI rounds of them); the other waves request their first rows at once.  One workgroup barrier separates
+//     staging from use; every wave's first rows are in flight before it.  With the OLDER half staging (the
+//     memory pipeline serves older waves first): 4096x11008 w4 6.98 -> 6.61 us per launch in a dependent chain, 6.40
+//     with nontemporal row loads; any other choice of staging waves (younger half, 1, 2, 3, 5, 6 of 8) is slower
+//     than all eight (lab_3.txt, lab_4.txt).
+//
+// Tried on this structure and not kept (tools/microbench/gemv_lab.hip at the commit that added this file,
+// profiles/r03/lab_1.txt, lab_2.txt): handing the units to the waves at run time from an LDS counter (the waves of a
+// workgroup then finish within 0.3 us of each other instead of 0.5, and the launch takes 0.5 us LONGER), a static
+// 5 : 3 split between the older and the younger wave of each SIMD (spread 0.13 us, launch +0.1 us), s_setprio for the
+// younger half (no change): a CU's time is set by its memory pipeline, not by its slowest wave.
+//
+// Arithmetic is exactly that of xbit_gemv_mfma.h: zs = fp16((z + bias) * s), W = fp16(fma(q, s, -zs)) through the
+// subnormal form when every scale of the tile allows it, the spliced form otherwise (decided per workgroup), fp32
+// accumulation in a fixed order - results are identical from launch to launch.
+#pragma once
+
+#include "xbit_device.h"
+#include "xbit_host.h"
+
+namespace xbit {
+
+namespace dyn {
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int CPL, bool NT>
+struct Row {
+  uint32_t v[CPL];
+  __device__ __forceinline__ void load(rsrc_t r, uint32_t voff, uint32_t soff) {
+    constexpr int aux = NT ? 2 : 0;
+    if constexpr (CPL == 2) {
+      const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux);
+      v[0] = t.x; v[1] = t.y;
+    } else if constexpr (CPL == 3) {
+      const u32x3_t t = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, aux);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z;
+    } else {
+      const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+
+// Which rows of a unit (UB k-blocks of BITS rows per lane) an MFMA step touches, and when rows are requested.
+// Step s = (k-block s / 4, octet s % 4).  Rows are numbered across the wave's consecutive units ("flat": 0..R-1 this
+// unit, R..2R-1 the next, 2R.. the one after); after step s the rows [need(s) + LA, need(s + 1) + LA) go out, so LA + 1
+// row loads are in flight when a step's last row is waited for.
+template <int BITS, int UB, int LA>
+struct Plan {
+  static constexpr int R = UB * BITS;  // row loads per lane and unit
+  static constexpr int S = UB * 4;     // MFMA steps per unit
+  static constexpr int need(int s) {   // rows (of this unit onward) that must have landed for step s; s == S: first step of the next unit
+    return s >= S ? R + need(s - S) : (s / 4) * BITS + Unpack<BITS>::rows_for_octet(s % 4);
+  }
+  static constexpr int first_row(int s) {  // lowest row step s reads (rows below it are dead once step s starts)
+    if (s >= S) return R;
+    const int j = s / 4, oct = s % 4;
+    if (Unpack<BITS>::kPow2) return j * BITS + (oct * 8 * BITS) / 32;
+    return j * BITS + (oct < 2 ? 0 : (16 * BITS) / 32);
+  }
+  static constexpr int open = need(0) + LA;  // rows requested before the first step
+  static_assert(open <= 2 * R, "the opening burst stays inside two units");
+  static_assert(need(S) + LA <= 3 * R, "requests run at most two units ahead");
+};
+
+struct DynParams {
+  const uint32_t* qweight;  // [kw, n]
+  uint32_t n, tiles, kw, units;  // units = ceil(k-blocks / (LK * UB)): wave w works on units w, w + NW, ...
+  const uint16_t* a;        // fp16 [k]
+  const uint16_t* scales;   // fp16 [groups, n]
+  const uint32_t* qzeros;   // [groups, zw]
+  uint16_t* out;            // fp16 [n]
+  uint32_t k, groups, zw, bias;
+  uint32_t tab_groups;      // rows of the LDS table: every group a k-slot of [0, LK * units) can name (>= groups; the extra rows are zeros)
+  uint32_t gshift;          // log2(groupsize / (32 * UB)): k-slot batch t = unit * LK + kl belongs to group t >> gshift
+  uint32_t act_bytes;       // LDS bytes of the staged activation vector: units * LK * UB * 64
+  uint64_t* trace;          // stamped build only
+};
+
+// Template parameters
+//   BITS   weight width 2..8        UB   k-blocks per lane and unit (groupsize % (32 * UB) == 0)
+//   CPL    adjacent columns per lane (2, 3, 4)      NL   lanes side by side along N (16: tiles of 16 * CPL columns; 8: the
+//          MFMA's 16 column slots are 8 columns x 2 k-slots, kept apart by feeding their activations to row blocks 0-7
+//          and 8-15 of the A operand, as in xbit_gemv_mfma.h)                       NW   waves per workgroup
+//   SI     staging rounds (each staging thread handles SI activation chunks and SI table entries; their loads all go
+//          out up front): the launcher picks the smallest of 1, 2, 4, 8 that covers the shape
+//   STW    waves that stage the small operands (the first STW); the other NW - STW go straight to their weight rows
+//   LA     row lookahead (see Plan)
+//   FLAGS  2 = per-wave stamps to p.trace (measurement builds)
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0>
+__global__ void __launch_bounds__(64 * NW)
+    gemv_dyn_kernel(const uint32_t* qweight, uint32_t n, uint32_t tiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales,
+                    const uint32_t* qzeros, uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t tab_groups, uint32_t gshift,
+                    uint32_t act_bytes, uint64_t* trace) {
+  // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
+  // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
+  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, tab_groups, gshift, act_bytes, trace};
+  using P = Plan<BITS, UB, LA>;
+  constexpr int R = P::R, S = P::S;
+  constexpr int LK = 64 / NL;   // k-slots per wave
+  constexpr int CN = NL * CPL;  // columns per workgroup
+  constexpr int HS = 16 / NL;   // NL = 8: the two k-slot parities land in different rows / column slots of D
+  constexpr bool STAMP = (FLAGS & 2) != 0;
+  constexpr int ST = 64 * STW;  // staging threads
+  constexpr int CHK = Unpack<BITS>::kChunkK;  // k per activation chunk (the span inside which the unpacker pairs fields)
+  constexpr int CPT = CHK / 8;                // 16-byte loads per chunk
+  constexpr uint32_t kOob = 0x80000000u;
+  static_assert(NL == 16 || NL == 8, "lanes along N");
+  static_assert(STW >= 1 && STW <= NW, "staging waves");
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  // LDS: [activations: act_bytes][table: tab_groups * NL lanes * 16 B][reduction: NW * HS * CN floats][bad flags: 8 dwords]
+  uint32_t* const s_act = s_dyn;
+  uint32_t* const s_tab = s_dyn + p.act_bytes / 4u;
+  float* const s_red = reinterpret_cast<float*>(s_tab + p.tab_groups * (uint32_t)(NL * 4));
+  uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * CN + 3) & ~3));
+
+  const int tid = threadIdx.x, lane = tid & 63, kl = lane / NL, nl = lane % NL;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: unit numbers ride in scalar offsets
+  uint64_t stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+  if constexpr (STAMP) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  const uint32_t tile = xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t row_bytes = p.n * 4u;
+  const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
+  const bool col_ok = col < p.n;
+  const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
+  const rsrc_t r_a = make_rsrc(p.a, (p.k * 2u + 3u) & ~3u);  // odd k: the last element's dword must be in range (its other half is masked below)
+  const rsrc_t r_s = make_rsrc(p.scales, p.groups * p.n * 2u);
+  const rsrc_t r_z = make_rsrc(p.qzeros, p.groups * p.zw * 4u);
+  const bool stager = wv < STW;  // wave-uniform
+
+  // ---- small operands, loads only (oldest in the queue: they return first) ----
+  // (a) activations: chunk c = k CHK*c .. CHK*c + CHK - 1; (b) per group and column: scale and zero-point of staging
+  // thread e's (group e / NL, lane slot e % NL).  Rounds past the end fall off the end of their tensors (the descriptors
+  // return zeros, no traffic); lane slots past the last column read some other column's values, which are never stored.
+  u32x4_t act_raw[SI][CPT];
+  uint32_t s_raw[SI][2], z_raw[SI][2];
+  if (stager) {
+#pragma unroll
+    for (int r = 0; r < SI; ++r) {
+      const uint32_t c = (uint32_t)(r * ST + tid);
+#pragma unroll
+      for (int q = 0; q < CPT; ++q)  // dwords past the end of the vector read 0; a last dword that holds ONE element is masked when staged
+        act_raw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, c * (uint32_t)(CHK * 2) + 16u * q, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < SI; ++r) {
+      const uint32_t e = (uint32_t)(r * ST + tid), g = e / NL, snl = e % NL;
+      const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
+      const uint32_t h0 = g * p.n + scol;  // first scale (half index)
+      if constexpr (CPL == 2) {
+        s_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b32(r_s, h0 * 2u, 0, 0);  // n and col even
+        s_raw[r][1] = 0;
+      } else {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_s, (h0 & ~1u) * 2u, 0, 0);
+        s_raw[r][0] = v.x;
+        s_raw[r][1] = v.y;
+      }
+      const uint32_t bit = scol * BITS;
+      const uint32_t zoff = (g * p.zw + (bit >> 5)) * 4u;
+      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
+        z_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0);  // the CPL fields never straddle a word
+        z_raw[r][1] = 0;
+      } else {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_z, zoff, 0, 0);  // a read past the row end is harmless
+        z_raw[r][0] = v.x;
+        z_raw[r][1] = v.y;
+      }
+    }
+  }
+
+  // ---- the first weight rows of this wave ----
+  // lane part of every row address: k-blocks kl * UB .. of the unit (BITS rows each), this lane's columns
+  const uint32_t lane_off = col_ok ? (uint32_t)(kl * R) * row_bytes + col * 4u : kOob;
+  const uint32_t unit_bytes = (uint32_t)(LK * R) * row_bytes;
+  Row<CPL, NT> ra[R], rb[R];
+  uint32_t cur = (uint32_t)wv, nxt = (uint32_t)(wv + NW), nn = (uint32_t)(wv + 2 * NW);
+  // Request flat rows [from, to) as seen from the unit in X: X = this unit, Y = the next, X again = the one after.
+  // A unit past the end reads through offsets beyond the descriptor's range: zeros, no traffic
+  // (host: (units + 3 * NW) * unit_bytes < 2^31).
+  auto request = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R], auto from_c, auto to_c) {
+    constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
+    static_for<(to > from ? to - from : 0)>([&](auto d) {
+      constexpr int f = from + decltype(d)::value;
+      if constexpr (f < R) X[f].load(r_w, lane_off, cur * unit_bytes + (uint32_t)f * row_bytes);
+      else if constexpr (f < 2 * R) Y[f - R].load(r_w, lane_off, nxt * unit_bytes + (uint32_t)(f - R) * row_bytes);
+      else X[f - 2 * R].load(r_w, lane_off, nn * unit_bytes + (uint32_t)(f - 2 * R) * row_bytes);
+    });
+  };
+  request(ra, rb, std::integral_constant<int, 0>{}, std::integral_constant<int, P::open>{});
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (STAMP) stamp[6] = __builtin_amdgcn_s_memrealtime();  // first rows requested
+
+  // ---- stage the small operands (waits for them only: the weight rows stay in flight) ----
+  bool bad = false;
+  if (stager) {
+#pragma unroll
+    for (int r = 0; r < SI; ++r) {
+      const uint32_t c = (uint32_t)(r * ST + tid);
+      uint32_t h[CHK / 2];
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        h[4 * q + 0] = act_raw[r][q].x;
+        h[4 * q + 1] = act_raw[r][q].y;
+        h[4 * q + 2] = act_raw[r][q].z;
+        h[4 * q + 3] = act_raw[r][q].w;
+      }
+      {
+        // k is any length: elements at k and beyond count as 0 (the packed rows hold padding fields there).  Only an odd
+        // k leaves something to clear - the upper half of the dword that holds element k - 1.
+        const int left = (int)p.k - (int)(c * (uint32_t)CHK);  // elements of this chunk inside the vector
+#pragma unroll
+        for (int d = 0; d < CHK / 2; ++d) h[d] = left >= 2 * d + 2 ? h[d] : (left == 2 * d + 1 ? (h[d] & 0xFFFFu) : 0u);
+      }
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // pair (4q + e) of this chunk in the unpacker's order; pair_k is periodic in the chunk
+          const int pr = 4 * q + e;
+          const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
+          static_assert(Unpack<BITS>::pair_k(CHK / 2 - 1, 1) < CHK, "pairs stay inside a chunk");
+          const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) | ((uint32_t)(4 + 2 * (khi & 1)) << 16) |
+                               ((uint32_t)(5 + 2 * (khi & 1)) << 24);
+          o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+        }
+        if (c * (uint32_t)(CHK * 2) < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_act + c * (uint32_t)(CHK / 2) + 4 * q) = o;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < SI; ++r) {
+      const uint32_t e = (uint32_t)(r * ST + tid), g = e / NL, snl = e % NL;
+      const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
+      uint32_t sb[CPL];
+      if constexpr (CPL == 2) {
+        sb[0] = s_raw[r][0] & 0xFFFFu;
+        sb[1] = s_raw[r][0] >> 16;
+      } else {
+        const uint32_t sh = ((g * p.n + scol) & 1u) * 16u;
+        const uint32_t lo = __builtin_amdgcn_alignbit(s_raw[r][1], s_raw[r][0], sh), hi = s_raw[r][1] >> sh;
+        sb[0] = lo & 0xFFFFu;
+        sb[1] = lo >> 16;
+        sb[2] = hi & 0xFFFFu;
+        if constexpr (CPL == 4) sb[3] = hi >> 16;
+      }
+      const uint32_t zsh = (scol * BITS) & 31u;
+      uint32_t zwin;
+      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) zwin = z_raw[r][0] >> zsh;
+      else zwin = __builtin_amdgcn_alignbit(z_raw[r][1], z_raw[r][0], zsh);
+      u32x4_t ent = {0u, 0u, 0u, 0u};  // (scale | -(zero + bias) * scale << 16) per column
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const _Float16 s = as_h((uint16_t)sb[c]);
+        const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + p.bias;
+        bool ok;
+        (void)sub_scale<BITS>(s, ok);
+        bad = bad || !ok;
+        ent[c] = (uint32_t)as_u16(s) | ((uint32_t)as_u16(neg_zero_times_scale(z, s)) << 16);
+      }
+      if (g < p.tab_groups) *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent;
+    }
+  }
+  {
+    const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (lane < 8 && (lane == wv || (wv == 0 && lane >= NW))) s_bad[lane] = (lane == wv && wave_bad) ? 1u : 0u;  // wave 0 also clears the unused slots
+  }
+  if constexpr (STAMP) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();
+  if constexpr (STAMP) stamp[2] = __builtin_amdgcn_s_memrealtime();
+  const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(s_bad), b1 = *reinterpret_cast<const u32x4_t*>(s_bad + 4);
+  const bool fast = __builtin_amdgcn_readfirstlane((int)(b0.x | b0.y | b0.z | b0.w | b1.x | b1.y | b1.z | b1.w)) == 0;
+
+  f4_t acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
+  const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
+  const uint32_t a_lane = (uint32_t)(kl * UB) * 16u;  // dwords: this lane's k-blocks of the unit, 4 octets x 4 dwords each
+
+  // per-unit dequant constants of this lane's columns
+  auto unit_consts = [&](uint32_t u, half2_t(&s2)[CPL], half2_t(&nzs2)[CPL], half2_t(&ss2)[CPL]) {
+    const uint32_t gi = (u * (uint32_t)LK + (uint32_t)kl) >> p.gshift;  // < tab_groups
+    const u32x4_t ent = *reinterpret_cast<const u32x4_t*>(s_tab + (gi * (uint32_t)NL + (uint32_t)nl) * 4u);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      s2[c] = as_h2(__builtin_amdgcn_perm(ent[c], ent[c], 0x01000100u));
+      nzs2[c] = as_h2(__builtin_amdgcn_perm(ent[c], ent[c], 0x03020302u));
+      // scale * 2^(14 + BITS) in two exact steps (the factor itself is not an fp16); finite for every scale of a tile that takes the subnormal form
+      constexpr int L = Unpack<BITS>::kSubScaleLog2;
+      ss2[c] = (s2[c] * splat((_Float16)(float)(1 << 8))) * splat((_Float16)(float)(1 << (L - 8)));
+    }
+  };
+  // one MFMA step: octet `oct` of k-block `j` of the unit whose rows are in X
+  auto step = [&](const Row<CPL, NT>(&X)[R], const uint32_t* a_unit, auto s_c, auto fast_c, const half2_t(&s2)[CPL], const half2_t(&nzs2)[CPL],
+                  const half2_t(&ss2)[CPL]) {
+    constexpr int s = decltype(s_c)::value, j = s / 4, oct = s % 4;
+    constexpr bool FAST = decltype(fast_c)::value;
+    const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + j * 16 + 4 * oct);
+    const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
+    uint32_t wc[CPL][BITS];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+      for (int i = 0; i < BITS; ++i) wc[c][i] = X[j * BITS + i].v[c];
+    u32x4_t braw[CPL];
+    static_for<4>([&](auto e_c) {
+      constexpr int e = decltype(e_c)::value, pr = 4 * oct + e;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        if constexpr (FAST) {
+          const uint32_t q = Unpack<BITS>::template sub_pair<pr>(wc[c], sub_mask);
+          braw[c][e] = as_u32(__builtin_elementwise_fma(as_h2(q), ss2[c], nzs2[c]));
+        } else {
+          const uint32_t q = Unpack<BITS>::template pair<pr>(wc[c], uk);
+          braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(q, s2[c], nzs2[c]));
+        }
+      }
+    });
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+  };
+
+  // one unit: its rows are in X (in flight or landed); behind each step the rows Plan schedules go out, into Y (next
+  // unit) and, once dead, back into X (the unit after that).  A unit past the end computes nothing and loads nothing real.
+  auto process = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R]) {
+    const bool live = cur < p.units;  // wave-uniform
+    half2_t s2[CPL], nzs2[CPL], ss2[CPL];
+    const uint32_t* const a_unit = s_act + cur * (uint32_t)(LK * UB * 16) + a_lane;
+    if (live) unit_consts(cur, s2, nzs2, ss2);
+    static_for<S>([&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      if (live) step(X, a_unit, s_c, std::true_type{}, s2, nzs2, ss2);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int from = P::need(s) + LA, to = P::need(s + 1) + LA;
+      // a row of the unit after next reuses a register of this unit: it must be dead by now
+      static_assert(to <= 2 * R || to - 1 - 2 * R < P::first_row(s + 1), "register of a live row reused");
+      request(X, Y, std::integral_constant<int, from>{}, std::integral_constant<int, to>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    cur = nxt;
+    nxt = nn;
+    nn += (uint32_t)NW;
+  };
+
+  if (fast) {
+    // units are taken two at a time so that the register sets keep their roles across the back edge
+    do {
+      process(ra, rb);
+      process(rb, ra);
+    } while (cur < p.units);
+  } else {
+    // some scale of the tile is too large for the subnormal form (or not finite): the spliced form, same W bit for bit.
+    // Not a path real checkpoints take: plain loop, own loads, units w, w + NW, ...
+    for (uint32_t u = (uint32_t)wv; u < p.units; u += (uint32_t)NW) {
+      half2_t s2[CPL], nzs2[CPL], ss2[CPL];
+      unit_consts(u, s2, nzs2, ss2);
+      Row<CPL, NT> rs[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) rs[i].load(r_w, lane_off, u * unit_bytes + (uint32_t)i * row_bytes);
+      const uint32_t* const a_unit = s_act + u * (uint32_t)(LK * UB * 16) + a_lane;
+      static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2); });
+    }
+  }
+  if constexpr (STAMP) {
+    asm volatile("" : "+v"(acc[0]));
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+  }
+
+  // ---- cross-wave sum.  D[row][slot]: row 4 * (lane >> 4) + r lives in register r of lane (lane >> 4, slot = lane & 15).
+  // NL = 16: row 0 (register 0 of lanes 0-15) is the sum over the wave's four k-slots for column slot = nl.
+  // NL = 8: even k-slots sum into D[0][0..7] (lanes 0-7), odd ones into D[8][8..15] (lanes 40-47). ----
+  {
+    const int h = NL == 16 ? 0 : (lane >= 32 ? 1 : 0);
+    const bool holder = NL == 16 ? lane < 16 : (lane < 8 || (lane >= 40 && lane < 48));
+    if (holder) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) s_red[(wv * HS + h) * CN + (lane % NL) * CPL + c] = acc[c][0];
+    }
+  }
+  __syncthreads();
+  if constexpr (STAMP) stamp[4] = __builtin_amdgcn_s_memrealtime();
+  if (tid < CN) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW * HS; ++w) sum += s_red[w * CN + tid];
+    const uint32_t n_out = tile * CN + (uint32_t)tid;
+    if (n_out < p.n) p.out[n_out] = as_u16((_Float16)sum);
+  }
+  if constexpr (STAMP) {
+    stamp[5] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && p.trace != nullptr) {
+      uint64_t* o = p.trace + ((size_t)blockIdx.x * NW + wv) * 8;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) o[i] = stamp[i];
+      // where the wave ran: XCC_ID (hwreg 20) above HW_ID (hwreg 4: wave, simd, cu, sh, se ids)
+      o[7] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+
+// LDS bytes of one workgroup (dynamic)
+inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl) {
+  const int hs = 16 / nl, cn = nl * cpl;
+  return (size_t)p.act_bytes + (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * cn + 3) & ~3) * 4u + 32u;
+}
+
+constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
+constexpr int kDynWaves = 8, kDynStagers = 4, kDynLookahead = 4;
+constexpr size_t kDynMaxLds = 96u << 10;  // larger staged operands (K beyond ~24 K at g128) stay with xbit_gemv_mfma.h
+
+template <int BITS>
+constexpr int dyn_ub() {
+  return BITS == 2 ? 2 : 1;  // >= 3 row loads per unit
+}
+
+template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0>
+int launch_dyn_one(const DynParams& p, hipStream_t stream) {
+  constexpr int UB = dyn_ub<BITS>();
+  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS>;
+  DynParams q = p;
+  void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias,
+                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.trace};
+  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles), dim3(64 * kDynWaves), dyn_lds_bytes(p, NL, kDynWaves, CPL), stream, args);
+}
+
+template <int BITS, int CPL, int NL, bool NT>
+int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool stamped) {
+#if XBIT_TUNING
+  if (stamped) {
+    if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 2>(p, stream);
+    return kDynNotEligible;
+  }
+#else
+  (void)stamped;
+#endif
+  if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2>(p, stream);
+  if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4>(p, stream);
+  if (rounds <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 8>(p, stream);
+  return kDynNotEligible;
+}
+
+// One-row GEMV through the staged-operand kernel, or kDynNotEligible.  `cpl` / `nl`: tile shape (16 * cpl columns, or
+// nl = 8: 8 * cpl); the caller picks them.  Eligible: one activation row (any k), group size a power-of-two multiple
+// of 32 * UB, 4-byte aligned tensors, staged operands within kDynMaxLds and 8 staging rounds, every byte offset below 2^31.
+template <int BITS>
+int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace) {
+  constexpr int UB = dyn_ub<BITS>();
+  if (g.m != 1u || g.groupsize % (32u * UB) != 0u) return kDynNotEligible;
+  if (((uintptr_t)g.a | (uintptr_t)g.qweight | (uintptr_t)g.scales | (uintptr_t)g.qzeros) % 4u != 0u) return kDynNotEligible;  // dword buffer loads
+  const uint32_t d = g.groupsize / (32u * UB);
+  if ((d & (d - 1u)) != 0u) return kDynNotEligible;
+  if (nl != 16 && !(nl == 8 && cpl == 2)) return kDynNotEligible;
+  DynParams p;
+  p.qweight = g.qweight;
+  p.n = g.n;
+  p.kw = g.kw;
+  p.a = g.a;
+  p.scales = g.scales;
+  p.qzeros = g.qzeros;
+  p.out = g.out;
+  p.k = g.k;
+  p.groups = g.groups;
+  p.zw = g.zw;
+  p.bias = g.bias;
+  p.trace = trace;
+  p.gshift = 0;
+  while ((1u << p.gshift) < d) ++p.gshift;
+  const uint32_t lk = 64u / (uint32_t)nl, kblocks = (g.k + 31u) / 32u;
+  p.tiles = (g.n + (uint32_t)(nl * cpl) - 1u) / (uint32_t)(nl * cpl);
+  p.units = (kblocks + lk * UB - 1u) / (lk * UB);
+  p.act_bytes = p.units * lk * UB * 64u;
+  p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
+  if (p.tab_groups < p.groups) p.tab_groups = p.groups;
+  if (dyn_lds_bytes(p, nl, kDynWaves, cpl) > kDynMaxLds) return kDynNotEligible;
+  const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
+  if (((uint64_t)p.units + 3u * kDynWaves) * unit_bytes >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
+  constexpr uint32_t st = 64u * kDynStagers;
+  const uint32_t chunks = p.act_bytes / (uint32_t)(Unpack<BITS>::kChunkK * 2);
+  const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
+  const uint32_t rounds = r_act > r_tab ? r_act : r_tab;
+#define XBIT_DYN(CPL_, NL_)                                                                      \
+  return nt ? launch_dyn_si<BITS, CPL_, NL_, true>(p, stream, rounds, stamped)                   \
+            : launch_dyn_si<BITS, CPL_, NL_, XBIT_TUNING ? false : true>(p, stream, rounds, stamped)
+  if (nl == 8) { XBIT_DYN(2, 8); }
+  if (cpl == 4) { XBIT_DYN(4, 16); }
+  if (cpl == 3) { XBIT_DYN(3, 16); }
+  XBIT_DYN(2, 16);
+#undef XBIT_DYN
+}
+
+}  // namespace dyn
+
+}  // namespace xbit

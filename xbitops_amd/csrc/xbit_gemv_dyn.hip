@@ -1,0 +1,28 @@
+// xbit_gemv_dyn.hip — bit-width dispatch for the staged-operand one-row GEMV.  The kernel template lives in
+// xbit_gemv_dyn.h and is instantiated once per bit-width in xbit_gemv_dyn_b{2..8}.hip so that the widths compile in parallel.
+#include "xbit_host.h"
+
+namespace xbit {
+
+int launch_gemv_dyn_b2(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+int launch_gemv_dyn_b3(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+int launch_gemv_dyn_b4(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+int launch_gemv_dyn_b5(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+int launch_gemv_dyn_b6(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+int launch_gemv_dyn_b7(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+int launch_gemv_dyn_b8(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);
+
+int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace) {
+  switch (bits) {
+    case 2: return launch_gemv_dyn_b2(p, stream, cpl, nl, nt, stamped, trace);
+    case 3: return launch_gemv_dyn_b3(p, stream, cpl, nl, nt, stamped, trace);
+    case 4: return launch_gemv_dyn_b4(p, stream, cpl, nl, nt, stamped, trace);
+    case 5: return launch_gemv_dyn_b5(p, stream, cpl, nl, nt, stamped, trace);
+    case 6: return launch_gemv_dyn_b6(p, stream, cpl, nl, nt, stamped, trace);
+    case 7: return launch_gemv_dyn_b7(p, stream, cpl, nl, nt, stamped, trace);
+    case 8: return launch_gemv_dyn_b8(p, stream, cpl, nl, nt, stamped, trace);
+    default: return XBIT_ERR_BITS;
+  }
+}
+
+}  // namespace xbit

@@ -1,0 +1,10 @@
+// xbit_gemv_dyn_b3.hip — 3-bit instantiation of the staged-operand one-row GEMV (see xbit_gemv_dyn.h).
+#include "xbit_gemv_dyn.h"
+
+namespace xbit {
+
+int launch_gemv_dyn_b3(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace) {
+  return dyn::launch_dyn_bits<3>(p, stream, cpl, nl, nt, stamped, trace);
+}
+
+}  // namespace xbit

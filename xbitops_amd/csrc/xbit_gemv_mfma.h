@@ -673,6 +673,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       uint64_t* o = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wv) * 8;
 #pragma unroll
       for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+      // where the wave ran: XCC_ID (hwreg 20) above HW_ID (hwreg 4: wave, simd, cu, sh, se ids); slot 6 as in xbit_gemv_dyn.h
+      o[6] = stamp[1];
+      o[7] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
   }
 }
@@ -942,22 +945,6 @@ constexpr int max_ub() {
   return BITS <= 4 ? 4 : 2;  // <= 16 outstanding row loads per lane
 }
 
-// Tiles are 16*CPL columns wide.  Prefer the width whose tile count wastes the fewest CU slots
-// (tiles / (ceil(tiles/256)*256)); ties go to the wider load (longer contiguous row segments).
-inline int pick_cpl(uint32_t n) {
-  int best = 2;
-  double best_eff = -1.0;
-  for (int cpl = 2; cpl <= 4; ++cpl) {
-    const uint32_t tiles = (n + 16u * cpl - 1) / (16u * cpl);
-    const double eff = (double)n / (16.0 * cpl) / (double)(((tiles + 255u) / 256u) * 256u);
-    if (eff >= best_eff - 1e-9) {
-      best_eff = eff;
-      best = cpl;
-    }
-  }
-  return best;
-}
-
 template <int BITS, int UB, bool NT = false>
 int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl, uint32_t wave_cap = 16u) {
   switch (cpl) {
@@ -1041,6 +1028,25 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
   constexpr uint32_t wave_cap = 16u;
   constexpr bool force_nt = false, force_plain = false;
 #endif
+  // One activation row (decode): the staged-operand kernel of xbit_gemv_dyn.h wherever it is eligible and the shape is
+  // not one that splits K over workgroups or takes the very wide tiles below (measured: profiles/r03/sweep_dyn_vs_mfma.txt).
+  // Tuning builds: variant 300 forces it (automatic tile), 301 16-column tiles (8 lanes x 8 B), 302-304 tiles of 32 / 48 /
+  // 64 columns, 310-314 the same with plain instead of nontemporal row loads, 320 stamped (tools/gemv_trace_detail.py),
+  // 399 never (the kernels of this file, for A/B).
+  auto try_dyn = [&](int auto_cpl, bool auto_small_n) -> int {
+    if (p.m != 1u) return kGemvDynNotEligible;
+    int dcpl = auto_small_n ? 2 : auto_cpl, dnl = auto_small_n ? 8 : 16;
+    bool nt = true, stamped = false;
+#if XBIT_TUNING
+    if (variant == 399 || (variant > 0 && (variant < 300 || variant > 320))) return kGemvDynNotEligible;
+    if (variant >= 310 && variant <= 314) nt = false;
+    const int v = variant >= 310 && variant <= 314 ? variant - 10 : variant;
+    if (v == 301) dcpl = 2, dnl = 8;
+    if (v >= 302 && v <= 304) dcpl = v - 300, dnl = 16;
+    if (variant == 320) stamped = true;
+#endif
+    return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, nt, stamped, opts.trace);
+  };
   if (p.groupsize % (32u * UBMAX) == 0) {
 #if XBIT_TUNING
     if (variant == 180 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 1024>(p, stream);  // 16-row pass, weights first
@@ -1221,6 +1227,14 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
         if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
       }
     }
+    {
+      const bool small_n = cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128;
+      const bool wide = (BITS == 4 || BITS == 8) && p.n >= 25600u && kblocks / UBMAX >= 32;
+      if (!wide || (XBIT_TUNING && variant >= 300)) {
+        const int st = try_dyn(cpl, small_n);
+        if (st != kGemvDynNotEligible) return st;
+      }
+    }
     // Few tiles (e.g. the 8192x3584 shard of a 70B FFN on 8 GPUs: 112 tiles of 32 columns; 4096x4096):
     // halve the tile width (NL = 8: 16 columns, the MFMA's column slots split into two k-slots) so
     // twice as many CUs get work, with 2 k-blocks per lane and sweep.  Measured: 8192x3584 7.6 -> 6.8 us,
@@ -1256,8 +1270,14 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
         GemvWorkspace ws;
         if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, 2>(p, stream, plan, ws);
       }
+      const int st = try_dyn(cpl, false);
+      if (st != kGemvDynNotEligible) return st;
       return launch_cpl<BITS, 2>(p, stream, cpl);
     }
+  }
+  {
+    const int st = try_dyn(cpl, false);
+    if (st != kGemvDynNotEligible) return st;
   }
   return launch_cpl<BITS, 1>(p, stream, cpl);
 }

@@ -107,11 +107,31 @@ int launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, 
   return launch_raw(reinterpret_cast<const void*>(kernel), grid, block, stream, ptrs);
 }
 
+// Tiles are 16*CPL columns wide.  Prefer the width whose tile count wastes the fewest CU slots
+// (tiles / (ceil(tiles/256)*256)); ties go to the wider load (longer contiguous row segments).
+inline int pick_cpl(uint32_t n) {
+  int best = 2;
+  double best_eff = -1.0;
+  for (int cpl = 2; cpl <= 4; ++cpl) {
+    const uint32_t tiles = (n + 16u * cpl - 1) / (16u * cpl);
+    const double eff = (double)n / (16.0 * cpl) / (double)(((tiles + 255u) / 256u) * 256u);
+    if (eff >= best_eff - 1e-9) {
+      best_eff = eff;
+      best = cpl;
+    }
+  }
+  return best;
+}
+
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
 int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);          // dispatcher (xbit_gemv.hip)
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);     // xbit_gemv_mfma.hip
 // fused launch over p.multi_* (M = 1); XBIT_ERR_SHAPE when the shape is not eligible (caller then launches one by one)
 int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
+// One activation row through the staged-operand kernel (xbit_gemv_dyn.h): tiles of 16 * cpl columns (nl = 16) or 16 columns
+// (nl = 8, cpl = 2).  Returns kGemvDynNotEligible when the shape is not for that kernel (the caller launches another).
+constexpr int kGemvDynNotEligible = 1 << 30;
+int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);  // xbit_gemv_dyn.hip
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);     // xbit_gidx.hip
 int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);
 

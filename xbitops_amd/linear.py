@@ -34,6 +34,26 @@ class QuantLinear(torch.nn.Module):
         self.register_buffer("perm", None)
         self.register_buffer("g_idx", None)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """A state dict saved from an act-order layer carries `perm` or `g_idx`; a freshly constructed layer has both as None
+        buffers, which torch would report as unexpected keys (strict) or drop without a word (strict=False) - leaving sorted
+        rows with no permutation, i.e. silently wrong results.  Adopt them here, and drop a local one the incoming dict lacks."""
+        for name, length in (("perm", self.in_features), ("g_idx", self.in_features)):
+            key = prefix + name
+            if key in state_dict:
+                t = state_dict[key]
+                if t.dim() != 1 or t.shape[0] != length:
+                    error_msgs.append("size mismatch for %s: expected a vector of %d row indices, got %s" % (key, length, tuple(t.shape)))
+                    state_dict = dict(state_dict)
+                    del state_dict[key]
+                    continue
+                if getattr(self, name) is None or getattr(self, name).shape != t.shape or getattr(self, name).dtype != t.dtype:
+                    setattr(self, name, torch.empty_like(t, device=self.qweight.device))
+            elif getattr(self, name) is not None:
+                setattr(self, name, None)  # the checkpoint is not (this kind of) act-order
+        self._plan = None
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     @classmethod
     def from_float(cls, weight_kn, bits: int, groupsize: int = 128, add_zero_bias: int = 0) -> "QuantLinear":
         """Round-to-nearest group quantisation of ``weight_kn[K, N]`` (torch or numpy, float)."""
