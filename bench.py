@@ -25,8 +25,10 @@ Printed JSON (one line, rank 0)
                        so the span holds device time only: K x (kernel + launch boundary,
                        `boundary_us_per_step`); `host_clock_ms_per_step` is the host's view (blocker included).
   roofline             algorithmic bytes per launch / mean KERNEL duration over >= 200 cold launches
-                       (whatever --steps says), each bracketed by HIP events on its own stream
-                       (hipExtLaunchKernel via xbit_profile_enable).  peak = 8000 GB/s (HBM3E spec).
+                       (whatever --steps says), each bracketed by its own pair of HIP events on its own stream
+                       (hipExtLaunchKernel via xbit_profile_series_begin/_end) and queued back to back like the
+                       launches of the timed region; `isolated_launch_avg_kernel_us` is the same kernel launched on
+                       an idle chip (host wait after every launch).  peak = 8000 GB/s (HBM3E spec).
                        `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/
                        when they were taken from THIS build of the library (sha256 match), else null.
   cpu_baseline         (N = 1) the oracle's C restatement (fused dequant + GEMV, OpenMP) for ~10 s, and
@@ -66,12 +68,13 @@ def parse_args(argv=None):
     ap.add_argument("--shape", default="", help="K,N,bits,group,M: another single-GPU workload (profiling configs 3 and 5)")
     ap.add_argument("--op", choices=("gemv", "dequant"), default="gemv", help="dequant: time xbit_dequant_f16 on the --shape instead (write-bound; SURVEY 8f rank 1)")
     ap.add_argument("--graph", action="store_true", help="one GPU: time a hipGraph replay of the K launches instead of queued eager launches")
-    ap.add_argument("--no-graph", action="store_true", help="accepted for compatibility (eager launches are the default)")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: time eager launches + eager collectives instead of one captured hipGraph of K x (GEMV + all-gather)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--roofline-launches", type=int, default=MIN_ROOFLINE_LAUNCHES, help="event-bracketed cold launches (at least 200)")
     ap.add_argument("--warm", action="store_true", help="also report the cache-resident kernel time (one weight copy)")
     ap.add_argument("--variant", type=int, default=-1, help="tuning builds only: GEMV launch-shape variant")
+    ap.add_argument("--spinup", type=int, default=0, help="untimed steps queued between the blocker and the first timed step (measurement probe)")
     return ap.parse_args(argv)
 
 
@@ -207,16 +210,42 @@ def main(argv=None):
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for the 1-GPU rehearsal below
     torch.cuda.set_device(dev)
+    class _StdoutToStderr:
+        """RCCL prints a version banner on STDOUT when a communicator is created; stdout carries the ONE JSON line."""
+
+        def __enter__(self):
+            sys.stdout.flush()
+            self._saved = os.dup(1)
+            os.dup2(2, 1)
+
+        def __exit__(self, *exc):
+            sys.stdout.flush()
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+
     backend = "none"
+    force_pg = world == 1 and os.environ.get("XBIT_BENCH_FORCE_PG") == "1"  # rehearsal: a ONE-rank RCCL group, so that the captured (GEMV + all-gather) path runs on a 1-GPU box
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))  # the communicator is created at the first collective
+            torch.cuda.synchronize()
+        backend = "nccl"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # nccl == RCCL on ROCm.  XBIT_BENCH_BACKEND=gloo rehearses the multi-rank control flow with
         # several ranks on ONE GPU (RCCL refuses two ranks per device); never used for reported numbers.
         backend = os.environ.get("XBIT_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.all_reduce(torch.zeros(1, device=dev if backend == "nccl" else "cpu"))  # creates the communicator (and its banner) now
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     lib = _lib.load()  # raises if the HIP library is missing
     gemv_opts = None
@@ -268,7 +297,8 @@ def main(argv=None):
     if args.op == "dequant":  # rotate the outputs too: [K, N] fp16 each, > 512 MB in total so that no write stays cached
         n_out_bufs = max(2, min(copies, (COLD_BYTES + 2 * k_in * n_local - 1) // (2 * k_in * n_local) + 1))
     outs = torch.empty((n_out_bufs, k_in if args.op == "dequant" else batch, n_local), dtype=torch.float16, device=dev)
-    gathered = torch.empty((n_out_bufs, world, batch, n_local), dtype=torch.float16, device=dev) if world > 1 else None
+    collective = world > 1 or force_pg  # every step ends with the all-gather of its output shards
+    gathered = torch.empty((n_out_bufs, world, batch, n_local), dtype=torch.float16, device=dev) if collective else None
     torch.cuda.synchronize()
 
     a_ptr = act.data_ptr()
@@ -294,7 +324,7 @@ def main(argv=None):
         sp = torch.cuda.current_stream(dev).cuda_stream
         for i in range(first, first + count):
             kernel_step(i, sp)
-            if world > 1:
+            if collective:
                 sharded.all_gather_output(gathered[i % n_out_bufs], outs[i % n_out_bufs])
 
     def barrier():
@@ -314,13 +344,28 @@ def main(argv=None):
     # enqueue time, so the event-to-event span holds device time only: K x (kernel + launch boundary).
     # (A hipGraph replay measures the same per step — tools/bench_timing_probe.py — once its first,
     # slower replay is out of the way; --graph times that instead.)
-    graph = None
-    if args.graph and world == 1:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            run_steps(W, K)
-        graph.replay()  # the first replay of a graph pays a one-off ~40 us on the device: untimed
-        torch.cuda.synchronize()
+    graph, graph_note = None, ""
+    if (args.graph and world == 1 and not collective) or (collective and backend == "nccl" and not args.no_graph):
+        # One GPU: on request.  Sharded layer over RCCL: by default - K x (GEMV + all-gather) recorded ONCE into a hipGraph
+        # and replayed, so that the timed region holds device time (kernel + collective) and not the host's ~5 us of
+        # enqueue per GEMV plus torch's per-collective launch path.  If the collective cannot be captured on this stack
+        # the region falls back to eager launches and says so.
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run_steps(W, K)
+            g.replay()  # the first replay of a graph pays a one-off ~40 us on the device: untimed
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as exc:  # noqa: BLE001 - any capture failure means "time it eagerly"
+            graph_note = "graph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc).splitlines()[0][:160] if str(exc) else "")
+            torch.cuda.synchronize()
+    ok = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank replays, or none does
+        if int(ok.item()) == 0 and graph is not None:
+            graph, graph_note = None, "graph capture failed on another rank; eager launches"
+
     stream = torch.cuda.current_stream(dev)
     blocker_cycles = 0
     if world == 1:
@@ -330,13 +375,15 @@ def main(argv=None):
         c1.record(stream)
         torch.cuda.synchronize()
         cycles_per_us = 1000000 / (c0.elapsed_time(c1) * 1e3)
-        blocker_cycles = int((100 + (0 if graph is not None else 12 * K)) * cycles_per_us)
+        blocker_cycles = int((100 + (0 if graph is not None else 12 * (K + args.spinup))) * cycles_per_us)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if blocker_cycles:
         torch.cuda._sleep(blocker_cycles)
+    if args.spinup and graph is None:
+        run_steps(W - args.spinup, args.spinup)  # untimed: the chip leaves the blocker's near-idle state before ev0
     ev0.record(stream)
     if graph is not None:
         graph.replay()
@@ -353,22 +400,72 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_host = float(t[0].item()), float(t[1].item())
 
-    # ---- kernel-only durations: HIP events bracketing each launch, >= 200 cold launches whatever K is
-    def profiled(n: int, rotate: bool):
+    # ---- kernel-only durations: HIP events bracketing each launch, >= 200 cold launches whatever K is.
+    # The launches are queued back to back behind a blocker (xbit_profile_series_*: one event pair per launch, no host
+    # wait in between), i.e. the kernel is timed as it runs inside the timed region above - in a dependent chain.  A
+    # launch that starts on an IDLE chip reads 0.3-1 us longer: its XCDs wake up to a microsecond apart
+    # (profiles/r03/trace_detail_v63.txt); that figure is kept beside it as `isolated_launch_avg_kernel_us`.
+    def profiled_chain(n: int, rotate: bool):
+        sp = torch.cuda.current_stream(dev).cuda_stream
+        if blocker_cycles:
+            torch.cuda._sleep(int((100 + 30 * n) * cycles_per_us))
+        _lib.check(lib.xbit_profile_series_begin(n), "xbit_profile_series_begin")
+        for i in range(n):
+            kernel_step(W + K + i if rotate else 0, sp)
+        buf, cnt = (ctypes.c_float * n)(), ctypes.c_int()
+        _lib.check(lib.xbit_profile_series_end(buf, n, ctypes.byref(cnt)), "xbit_profile_series_end")
+        return [buf[i] for i in range(cnt.value)]
+
+    def profiled_isolated(n: int):
         lib.xbit_profile_enable(1)
         ms = ctypes.c_float()
         vals = []
         sp = torch.cuda.current_stream(dev).cuda_stream
         for i in range(n):
-            kernel_step(W + K + i if rotate else 0, sp)
+            kernel_step(W + K + i, sp)
             _lib.check(lib.xbit_profile_last_ms(ctypes.byref(ms)), "xbit_profile_last_ms")
             vals.append(ms.value)
         lib.xbit_profile_enable(0)
         return vals
 
-    profiled(8, True)
-    cold = profiled(max(MIN_ROOFLINE_LAUNCHES, args.roofline_launches), True)
-    warm = profiled(200, False) if args.warm else None
+    # the collective alone (K all-gathers of one step's shards, captured like the timed region when that was): what the
+    # xGMI hop costs per step, reported beside the kernel and the end-to-end figure
+    collective_us = None
+    if collective:
+        def gathers(count):
+            for i in range(count):
+                sharded.all_gather_output(gathered[i % n_out_bufs], outs[i % n_out_bufs])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cg = None
+        if graph is not None:
+            try:
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    gathers(K)
+                cg.replay()
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                cg = None
+                torch.cuda.synchronize()
+        gathers(8)
+        barrier()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        if cg is not None:
+            cg.replay()
+        else:
+            gathers(K)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / K], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        collective_us = float(t.item())
+
+    profiled_chain(8, True)
+    cold = profiled_chain(max(MIN_ROOFLINE_LAUNCHES, args.roofline_launches), True)
+    warm = profiled_chain(200, False) if args.warm else None
+    isolated = profiled_isolated(50)
     torch.cuda.synchronize()
     cold_avg = sum(cold) / len(cold)
     cold_sorted = sorted(cold)
@@ -402,14 +499,16 @@ def main(argv=None):
                 "bits": bits, "groupsize": group, "batch": batch, "in_features": k_in, "out_features_per_gpu": n_local,
                 "algorithmic_bytes_per_step": nbytes, "weight_copies_rotated": copies,
                 "timed_region": ("hipGraph replay of K launches" if graph is not None else "K eager launches") + (
-                    " queued behind a blocker kernel" if world == 1 else " + K all-gathers") + ", HIP events on the compute stream",
+                    " + K all-gathers" if collective else " queued behind a blocker kernel") + ", HIP events on the compute stream" + (
+                    "; " + graph_note if graph_note else ""),
                 "host_enqueue_us_per_step": round(1e6 * t_queued / K, 3),
                 "parallelism": ("column shards x%d (sharded.shard_columns) + one %s all_gather_into_tensor per step on the compute stream" % (
-                    world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
+                    world, "RCCL" if backend == "nccl" else backend)) if collective else "single GPU",
             },
             "host_clock_ms_per_step": round(1e3 * dt_host / K, 6),
             "end_to_end_us_per_step": round(1e6 * dt / K, 3),
             "boundary_us_per_step": round(1e6 * dt / K - cold_avg * 1e3, 3),  # dependent-launch boundary (+ the all-gather on N > 1)
+            "collective_us_per_step": None if collective_us is None else round(collective_us, 3),  # the all-gather alone, same launch mode
             "kernel_gbps_per_gpu": round(achieved, 2),
             "aggregate_kernel_gbps": round(world * achieved, 2),
             "roofline": {
@@ -419,7 +518,9 @@ def main(argv=None):
                 "algorithmic_bytes": nbytes,
                 "kernel": "xbit_gemv_f16 dominant kernel (see profiles/ for its name)", "avg_kernel_us": round(cold_avg * 1e3, 3),
                 "median_kernel_us": round(cold_sorted[len(cold_sorted) // 2] * 1e3, 3), "min_kernel_us": round(cold_sorted[0] * 1e3, 3),
-                "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch, cold weights" + (", max over GPUs" if world > 1 else ""),
+                "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch, launches queued back to back (a dependent chain, as in the timed region), cold weights" + (
+                    ", max over GPUs" if world > 1 else ""),
+                "isolated_launch_avg_kernel_us": round(1e3 * sum(isolated) / len(isolated), 3),
             },
             "offline_profile": off,
             "tok_per_s_proxy": round(achieved * 1e9 / 3.37e9, 1) if cfg_name == "cfg2" else None,
@@ -435,8 +536,9 @@ def main(argv=None):
             port["torch_cpu"] = cpu_baseline_torch(prob, y_port, bits, group, k_in, nbytes, args.cpu_seconds)
             rec["cpu_baseline"] = port
         print(json.dumps(rec), flush=True)
-    if world > 1:
-        dist.barrier()
+    if world > 1 or force_pg:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -107,7 +107,15 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
 typedef struct xbit_gemv_options {
   uint32_t struct_bytes;
   int32_t split_k;          /* 0 = choose (default); 1 = never split K; 2..15 = split K that many ways when the
-                               shape has a fast path (otherwise ignored).  Results differ only in summation order. */
+                               shape has a fast path (otherwise ignored).  Results differ only in summation order,
+                               with ONE exception, the numeric contract of a split launch: the K ranges meet in 64-bit
+                               fixed-point accumulators (2^-28 units).  While every range's partial sum stays inside
+                               +-2^19 (8 x the largest finite fp16) the result is the exact sum of the partials rounded
+                               once - cancellation between ranges included.  A partial sum beyond that saturates: the
+                               output is +-Inf (NaN if both signs occur) even where the unsplit fp32 sum would have
+                               cancelled back into range - it takes |W * a| ~ 1e2 per term over thousands of terms with an
+                               fp16-representable total.  The automatic choice (0) splits only few-column, long-K shapes
+                               (n <= ~5600 and k >= 8192 at one to four rows); pass 1 for the unsplit contract everywhere. */
   void* workspace;          /* caller-owned split-K scratch: device memory, zero-filled, >= xbit_gemv_workspace_bytes(m, n),
                                used by ONE launch at a time (it is zero again when that launch has finished).  NULL
                                (default) = library-managed, see "State" above. */
@@ -165,6 +173,14 @@ int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void*
  * Returns 0, a negative XBIT_ERR_*, or a positive hipError_t. */
 int xbit_profile_enable(int on);
 int xbit_profile_last_ms(float* ms);
+/* The same for a SERIES of launches queued back to back: after xbit_profile_series_begin(capacity) every launch of the
+ * calling thread gets its own event pair (up to `capacity` launches; further ones run untimed) and nothing waits on
+ * the host, so the device sees the launches as a dependent chain - a kernel that starts on an idle chip pays up to a
+ * microsecond of XCD wake-up skew that a kernel inside a chain does not (profiles/r03/trace_detail_v63.txt).
+ * xbit_profile_series_end waits for the last launch, writes the durations (milliseconds, launch order) of the first
+ * min(launches, capacity, max_count) launches to `ms`, their number to `*count`, and leaves profiling disabled. */
+int xbit_profile_series_begin(int capacity);
+int xbit_profile_series_end(float* ms, int max_count, int* count);
 
 #ifdef __cplusplus
 }

@@ -19,25 +19,72 @@ from xbitops_amd import _lib, synth  # noqa: E402
 COLD_BYTES = 512 << 20
 
 
+_CYCLES_PER_US = None
+
+
+def _blocker(us: float) -> None:
+    """Keep the stream busy for ~`us` microseconds so that the launches queued behind it run back to back."""
+    global _CYCLES_PER_US
+    if _CYCLES_PER_US is None:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        torch.cuda._sleep(1000000)
+        c1.record()
+        torch.cuda.synchronize()
+        _CYCLES_PER_US = 1000000 / (c0.elapsed_time(c1) * 1e3)
+    torch.cuda._sleep(int(us * _CYCLES_PER_US))
+
+
 def measure(lib, fn, n=200, warm=10):
+    """Per-launch kernel durations (hipExtLaunchKernel events) of `n` launches queued back to back behind a blocker -
+    the kernel as it runs inside a dependent chain.  (A launch on an idle chip reads 0.3-1 us longer: XCD wake-up skew;
+    XBIT_SWEEP_ISOLATED=1 measures that instead, with a host wait after every launch, as rounds 1-2 did.)"""
     ms = ctypes.c_float()
     for i in range(warm):
         fn(i)
     torch.cuda.synchronize()
-    lib.xbit_profile_enable(1)
     vals = []
-    for i in range(n):
-        fn(warm + i)
-        _lib.check(lib.xbit_profile_last_ms(ctypes.byref(ms)), "profile")
-        vals.append(ms.value * 1e3)
-    lib.xbit_profile_enable(0)
+    if os.environ.get("XBIT_SWEEP_ISOLATED"):
+        lib.xbit_profile_enable(1)
+        for i in range(n):
+            fn(warm + i)
+            _lib.check(lib.xbit_profile_last_ms(ctypes.byref(ms)), "profile")
+            vals.append(ms.value * 1e3)
+        lib.xbit_profile_enable(0)
+    else:
+        _blocker(100 + 30 * n)
+        _lib.check(lib.xbit_profile_series_begin(n), "profile series")
+        for i in range(n):
+            fn(warm + i)
+        buf, cnt = (ctypes.c_float * n)(), ctypes.c_int()
+        _lib.check(lib.xbit_profile_series_end(buf, n, ctypes.byref(cnt)), "profile series")
+        vals = [buf[i] * 1e3 for i in range(cnt.value)]
     vals.sort()
     return sum(vals) / len(vals), vals[len(vals) // 2], vals[0]
+
+
+def chain_period(fn, n=200, first=0, reps=3):
+    """Microseconds per launch of `n` launches queued back to back behind a blocker, between two events on the stream
+    (no per-launch events): kernel + launch boundary, what a decoder pays per layer.  Median of `reps`."""
+    out = []
+    for r in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        _blocker(100 + 12 * n)
+        e0.record()
+        for i in range(n):
+            fn(first + r * n + i)
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / n)
+    out.sort()
+    return out[len(out) // 2]
 
 
 def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, split=0):
     nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
     copies = (COLD_BYTES + nbytes - 1) // nbytes + 1 if cold else 1
+    warm_launches = 2 * copies if cold else 10  # every copy touched before the timed launches (a first touch pays page-table walks)
     base = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
     act = torch.from_numpy(base.act).to(dev)
     qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
@@ -63,7 +110,10 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, spli
         st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, o)
         assert st == 0, st
 
-    avg, med, mn = measure(lib, fn, iters)
+    avg, med, mn = measure(lib, fn, iters, warm_launches)
+    if os.environ.get("XBIT_SWEEP_PERIOD"):  # report the chain period instead of the kernel's own duration (same tuple layout)
+        per = chain_period(fn, iters, warm_launches + iters)
+        return nbytes, per, per, mn
     return nbytes, avg, med, mn
 
 

@@ -31,7 +31,9 @@ def main():
     dev = torch.device("cuda", 0)
     lib = _lib.load_tuning()
     variants = [int(v) for v in args.variants.split(",")]
-    print("# median us per launch (events, cold); group %d; columns: variant %s" % (args.group, " ".join(str(v) for v in variants)), flush=True)
+    print("# us per launch, cold, group %d: %s; columns: variant %s" % (
+        args.group, "period of a dependent chain of launches" if os.environ.get("XBIT_SWEEP_PERIOD") else "median kernel duration inside a chain (per-launch events)",
+        " ".join(str(v) for v in variants)), flush=True)
     for shape in args.shapes.split(","):
         k, n = (int(x) for x in shape.split("x"))
         for bits in (int(b) for b in args.bits.split(",")):

@@ -30,6 +30,8 @@ EXPORTS = (
     "xbit_gemv_multi_f16",
     "xbit_profile_enable",
     "xbit_profile_last_ms",
+    "xbit_profile_series_begin",
+    "xbit_profile_series_end",
 )
 
 _lib = None
@@ -90,6 +92,10 @@ def _typed(path: str) -> ctypes.CDLL:
     lib.xbit_profile_enable.argtypes = [ci]
     lib.xbit_profile_last_ms.restype = ci
     lib.xbit_profile_last_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    lib.xbit_profile_series_begin.restype = ci
+    lib.xbit_profile_series_begin.argtypes = [ci]
+    lib.xbit_profile_series_end.restype = ci
+    lib.xbit_profile_series_end.argtypes = [ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
     if lib.xbit_abi_version() != ABI_VERSION:
         raise XbitLibraryError("xbitops: ABI version mismatch (library %d, binding %d); rebuild" % (lib.xbit_abi_version(), ABI_VERSION))
     return lib

@@ -57,7 +57,10 @@ int launch_raw_dynamic(const void* kernel, dim3 grid, dim3 block, size_t dynamic
     const int st = raise_lds_limit(kernel);
     if (st != XBIT_OK) return st;
   }
-  if (ps.enabled) {
+  if (ps.series && ps.series_used < ps.series_capacity) {
+    err = hipExtLaunchKernel(kernel, grid, block, args, dynamic_lds, stream, ps.series_events[2 * ps.series_used], ps.series_events[2 * ps.series_used + 1], 0);
+    if (err == hipSuccess) ++ps.series_used;
+  } else if (ps.enabled) {
     err = hipExtLaunchKernel(kernel, grid, block, args, dynamic_lds, stream, ps.start, ps.stop, 0);
     ps.pending = (err == hipSuccess);
   } else {
@@ -402,6 +405,43 @@ int xbit_profile_enable(int on) {
   }
   ps.enabled = on != 0;
   ps.pending = false;
+  return XBIT_OK;
+}
+
+int xbit_profile_series_begin(int capacity) {
+  if (capacity < 1 || capacity > (1 << 20)) return XBIT_ERR_SHAPE;
+  xbit::ProfileState& ps = xbit::profile_state();
+  while ((int)ps.series_events.size() < 2 * capacity) {
+    hipEvent_t e = nullptr;
+    const hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess) {
+      (void)hipGetLastError();
+      return (int)err;
+    }
+    ps.series_events.push_back(e);
+  }
+  ps.series = true;
+  ps.series_used = 0;
+  ps.series_capacity = capacity;
+  return XBIT_OK;
+}
+
+int xbit_profile_series_end(float* ms, int max_count, int* count) {
+  if (!ms || !count) return XBIT_ERR_NULL_POINTER;
+  xbit::ProfileState& ps = xbit::profile_state();
+  if (!ps.series) return XBIT_ERR_SHAPE;
+  ps.series = false;
+  const int n = ps.series_used < max_count ? ps.series_used : (max_count > 0 ? max_count : 0);
+  *count = 0;
+  if (ps.series_used > 0) {
+    hipError_t err = hipEventSynchronize(ps.series_events[2 * (ps.series_used - 1) + 1]);  // the stream runs them in order
+    for (int i = 0; i < n && err == hipSuccess; ++i) err = hipEventElapsedTime(&ms[i], ps.series_events[2 * i], ps.series_events[2 * i + 1]);
+    if (err != hipSuccess) {
+      (void)hipGetLastError();
+      return (int)err;
+    }
+  }
+  *count = n;
   return XBIT_OK;
 }
 

@@ -376,7 +376,7 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
   // One row of any length k (the reference harness's own K = 7167, main.cc:21): the staged-operand kernel masks the tail
   // of the activation vector itself, so only group sizes that are not a multiple of 32 (or tensors that are not even
   // 4-byte aligned, or 2 GiB and more) go on to the column kernel below.
-  if (p.m == 1u && small && p.groupsize % 32u == 0 && !(XBIT_TUNING && opts.variant == 399)) {
+  if (p.m == 1u && small && p.groupsize % 32u == 0 && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
     const int st = launch_gemv_dyn(p, bits, stream, pick_cpl(p.n), 16, true, false, nullptr);
     if (st != kGemvDynNotEligible) return st;
   }

@@ -460,7 +460,10 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #else
   (void)stamped;
 #endif
+  // one build per count of staging rounds (2: K <= 4096 at group 128; 3: K = 5120; 4: K <= 8192; 8: up to 16384).  A build
+  // that skips unneeded rounds at run time instead took 0.9 us longer per launch (profiles/r03/lab_9.txt, lab_10.txt).
   if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2>(p, stream);
+  if (rounds <= 3u) return launch_dyn_one<BITS, CPL, NL, NT, 3>(p, stream);
   if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4>(p, stream);
   if (rounds <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 8>(p, stream);
   return kDynNotEligible;

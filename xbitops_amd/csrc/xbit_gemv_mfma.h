@@ -1032,13 +1032,14 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
   // not one that splits K over workgroups or takes the very wide tiles below (measured: profiles/r03/sweep_dyn_vs_mfma.txt).
   // Tuning builds: variant 300 forces it (automatic tile), 301 16-column tiles (8 lanes x 8 B), 302-304 tiles of 32 / 48 /
   // 64 columns, 310-314 the same with plain instead of nontemporal row loads, 320 stamped (tools/gemv_trace_detail.py),
-  // 399 never (the kernels of this file, for A/B).
+  // 399 never (the whole-K kernels of this file, unsplit, for A/B), 398 never, but with this file's own launch rules (split-K
+  // included): the round-2 library.
   auto try_dyn = [&](int auto_cpl, bool auto_small_n) -> int {
     if (p.m != 1u) return kGemvDynNotEligible;
     int dcpl = auto_small_n ? 2 : auto_cpl, dnl = auto_small_n ? 8 : 16;
     bool nt = true, stamped = false;
 #if XBIT_TUNING
-    if (variant == 399 || (variant > 0 && (variant < 300 || variant > 320))) return kGemvDynNotEligible;
+    if (variant == 399 || variant == 398 || (variant > 0 && (variant < 300 || variant > 320))) return kGemvDynNotEligible;
     if (variant >= 310 && variant <= 314) nt = false;
     const int v = variant >= 310 && variant <= 314 ? variant - 10 : variant;
     if (v == 301) dcpl = 2, dnl = 8;
@@ -1217,7 +1218,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       }
       if ((variant == 202 || variant == 205) && plan.splits >= 2) {  // sweep hook (tuning builds): force the tile width
         plan.cpl = variant == 202 ? 2 : 4;
-      } else if (variant > 0) {
+      } else if (variant > 0 && variant != 398) {
         plan.splits = 0;  // another measurement variant was asked for
       }
       if (plan.splits >= 2) {
@@ -1228,9 +1229,16 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       }
     }
     {
+      // Where the staged-operand kernel wins (chain period, profiles/r03/sweep_dyn_vs_mfma_period.txt): column tiles for
+      // most of the chip (>= 192 whole-K tiles, or the 16-column tiles of few-column layers from 3 bits up), and the
+      // wide-word widths everywhere (5/6/7-bit: 4096x14336 17.8 -> 9.0 us at 5 bits).  Not 2-bit with few columns
+      // (4096x4096: 4.1 against 4.5 us), not the 128-column-tile shapes of 4/8-bit below, not 160-tile layers at 2-4 and
+      // 8 bits (5120x5120 w4: 6.4 against 7.4: ten waves per workgroup there against this kernel's eight).
       const bool small_n = cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128;
       const bool wide = (BITS == 4 || BITS == 8) && p.n >= 25600u && kblocks / UBMAX >= 32;
-      if (!wide || (XBIT_TUNING && variant >= 300)) {
+      const uint32_t dyn_tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
+      const bool wins = small_n ? BITS >= 3 : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
+      if ((wins && !wide) || (XBIT_TUNING && variant >= 300)) {
         const int st = try_dyn(cpl, small_n);
         if (st != kGemvDynNotEligible) return st;
       }
@@ -1263,7 +1271,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       // group size 64 at 2-4 bits: 2 k-blocks per lane.  Few column tiles and long K split here too (4-bit 11008x4096
       // g64: 10.5 us unsplit; profiles/r02/sweep_group_sizes.txt); the occupancy table is that of the 4-k-block builds,
       // which hold a few registers more (conservative)
-      SplitPlan plan = (variant > 0) ? SplitPlan{} : plan_split(p, 2, opts.split, BITS);
+      SplitPlan plan = (variant > 0 && variant != 398) ? SplitPlan{} : plan_split(p, 2, opts.split, BITS);
       if (plan.splits >= 2) {
         const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
         const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/xbitops_hip.h"
 
 namespace xbit {
@@ -91,6 +93,10 @@ struct ProfileState {
   bool enabled = false;
   bool pending = false;
   hipEvent_t start = nullptr, stop = nullptr;
+  // series mode (xbit_profile_series_begin / _end): one event pair per launch, no host wait in between
+  bool series = false;
+  int series_used = 0, series_capacity = 0;
+  std::vector<hipEvent_t> series_events;  // start, stop, start, stop, ...
 };
 ProfileState& profile_state();
 

@@ -12,7 +12,10 @@ import torch
 
 from . import ops, packing
 
-GEMV_MAX_ROWS = 16  # rows handled by one pass of the fused kernel; above this dequant + GEMM wins
+# Rows served by the fused kernel.  One pass takes up to 16 rows; 17..32 rows are two passes over the packed weights
+# (4096x11008 w4: 14.6-15.2 us, profiles/r02/sweep_rows_per_call.txt), which still beats dequantising the layer first
+# (19.2 us for the dequant alone, before the dense GEMM); beyond that dequant + GEMM takes over.
+GEMV_MAX_ROWS = 32
 
 
 class QuantLinear(torch.nn.Module):
