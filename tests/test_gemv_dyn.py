@@ -152,3 +152,16 @@ def test_column_kernel_takes_misaligned_tensors(cuda_device):
     _lib.check(st, "xbit_gemv_f16")
     torch.cuda.synchronize()
     _close(out.cpu().numpy(), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), "misaligned")
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+@pytest.mark.parametrize("variant", [330, 332, 334])
+def test_split_k_build_vs_oracle(bits, variant, cuda_device):
+    """Few column tiles, long K: K cut into ranges that meet in the fixed-point accumulators (tuning library: the planned
+    split with the planned / 32-column / 64-column tiles through the staged-operand kernel's split build)."""
+    lib = _lib.load_tuning()
+    for k, n, g in [(8192, 3584, 128), (11008, 4096, 128), (16384, 1024, 128), (8192, 1030, 64)]:
+        p = synth.make_problem(k, n, bits, g, m=1, seed=bits * 17 + variant + k)
+        y = _run(lib, p, 1, cuda_device, variant)
+        _close(y, _ref(p, 1), (bits, variant, k, n, g))
+        assert np.array_equal(_bits(y), _bits(_run(lib, p, 1, cuda_device, variant)))  # arrival order does not matter: integer sums

@@ -97,7 +97,9 @@ struct DynParams {
   uint32_t k, groups, zw, bias;
   uint32_t tab_groups;      // rows of the LDS table: every group a k-slot of [0, LK * units) can name (>= groups; the extra rows are zeros)
   uint32_t gshift;          // log2(groupsize / (32 * UB)): k-slot batch t = unit * LK + kl belongs to group t >> gshift
-  uint32_t act_bytes;       // LDS bytes of the staged activation vector: units * LK * UB * 64
+  uint32_t act_bytes;       // LDS bytes of the staged activation vector: (units of one K range) * LK * UB * 64
+  uint32_t splits, ups;     // split-K builds: K ranges per tile and units per range (whole-K: 1, units)
+  unsigned long long* acc;  // split-K builds: one 64-bit accumulator per output element, zero between launches
   uint64_t* trace;          // stamped build only
 };
 
@@ -111,14 +113,17 @@ struct DynParams {
 //   STW    waves that stage the small operands (the first STW); the other NW - STW go straight to their weight rows
 //   LA     row lookahead (see Plan)
 //   FLAGS  2 = per-wave stamps to p.trace (measurement builds)
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0>
+//   SPLIT  split-K: workgroup (tile, split) sums units [split * ups, (split + 1) * ups) only and stages only that range's
+//          activations and groups; the partial sums meet in per-element 64-bit fixed-point accumulators exactly as in
+//          xbit_gemv_mfma.h (one returning atomic per element and workgroup; the last arriver converts, stores and clears)
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * NW)
     gemv_dyn_kernel(const uint32_t* qweight, uint32_t n, uint32_t tiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales,
                     const uint32_t* qzeros, uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t tab_groups, uint32_t gshift,
-                    uint32_t act_bytes, uint64_t* trace) {
+                    uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, uint64_t* trace) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, tab_groups, gshift, act_bytes, trace};
+  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, tab_groups, gshift, act_bytes, splits, ups, split_acc, trace};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
@@ -142,7 +147,12 @@ __global__ void __launch_bounds__(64 * NW)
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: unit numbers ride in scalar offsets
   uint64_t stamp[7] = {0, 0, 0, 0, 0, 0, 0};
   if constexpr (STAMP) stamp[0] = __builtin_amdgcn_s_memrealtime();
-  const uint32_t tile = xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
+  const uint32_t tile = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);
+  // this workgroup's units [ubeg, uend) and the first activation chunk / group that its LDS images start at
+  const uint32_t ubeg = SPLIT ? split * p.ups : 0u;
+  const uint32_t uend = SPLIT ? (ubeg + p.ups < p.units ? ubeg + p.ups : p.units) : p.units;
+  const uint32_t cbase = ubeg * (uint32_t)(LK * UB * (32 / CHK)), gbase = (ubeg * (uint32_t)LK) >> p.gshift;
   const uint32_t row_bytes = p.n * 4u;
   const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
   const bool col_ok = col < p.n;
@@ -164,11 +174,11 @@ __global__ void __launch_bounds__(64 * NW)
       const uint32_t c = (uint32_t)(r * ST + tid);
 #pragma unroll
       for (int q = 0; q < CPT; ++q)  // dwords past the end of the vector read 0; a last dword that holds ONE element is masked when staged
-        act_raw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, c * (uint32_t)(CHK * 2) + 16u * q, 0, 0);
+        act_raw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, (SPLIT && c * (uint32_t)(CHK * 2) >= p.act_bytes) ? kOob : (cbase + c) * (uint32_t)(CHK * 2) + 16u * q, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < SI; ++r) {
-      const uint32_t e = (uint32_t)(r * ST + tid), g = e / NL, snl = e % NL;
+      const uint32_t e = (uint32_t)(r * ST + tid), g = gbase + e / NL, snl = e % NL;
       const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
       const uint32_t h0 = g * p.n + scol;  // first scale (half index)
       if constexpr (CPL == 2) {
@@ -197,17 +207,18 @@ __global__ void __launch_bounds__(64 * NW)
   const uint32_t lane_off = col_ok ? (uint32_t)(kl * R) * row_bytes + col * 4u : kOob;
   const uint32_t unit_bytes = (uint32_t)(LK * R) * row_bytes;
   Row<CPL, NT> ra[R], rb[R];
-  uint32_t cur = (uint32_t)wv, nxt = (uint32_t)(wv + NW), nn = (uint32_t)(wv + 2 * NW);
+  uint32_t cur = ubeg + (uint32_t)wv, nxt = cur + (uint32_t)NW, nn = cur + (uint32_t)(2 * NW);
   // Request flat rows [from, to) as seen from the unit in X: X = this unit, Y = the next, X again = the one after.
-  // A unit past the end reads through offsets beyond the descriptor's range: zeros, no traffic
-  // (host: (units + 3 * NW) * unit_bytes < 2^31).
+  // A unit past the end of this workgroup's range reads from the descriptor's end on: zeros, no traffic.
+  const uint32_t past_end = p.kw * row_bytes;
+  auto unit_off = [&](uint32_t u) -> uint32_t { return u < uend ? u * unit_bytes : past_end; };
   auto request = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R], auto from_c, auto to_c) {
     constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
     static_for<(to > from ? to - from : 0)>([&](auto d) {
       constexpr int f = from + decltype(d)::value;
-      if constexpr (f < R) X[f].load(r_w, lane_off, cur * unit_bytes + (uint32_t)f * row_bytes);
-      else if constexpr (f < 2 * R) Y[f - R].load(r_w, lane_off, nxt * unit_bytes + (uint32_t)(f - R) * row_bytes);
-      else X[f - 2 * R].load(r_w, lane_off, nn * unit_bytes + (uint32_t)(f - 2 * R) * row_bytes);
+      if constexpr (f < R) X[f].load(r_w, lane_off, unit_off(cur) + (uint32_t)f * row_bytes);
+      else if constexpr (f < 2 * R) Y[f - R].load(r_w, lane_off, unit_off(nxt) + (uint32_t)(f - R) * row_bytes);
+      else X[f - 2 * R].load(r_w, lane_off, unit_off(nn) + (uint32_t)(f - 2 * R) * row_bytes);
     });
   };
   request(ra, rb, std::integral_constant<int, 0>{}, std::integral_constant<int, P::open>{});
@@ -231,7 +242,7 @@ __global__ void __launch_bounds__(64 * NW)
       {
         // k is any length: elements at k and beyond count as 0 (the packed rows hold padding fields there).  Only an odd
         // k leaves something to clear - the upper half of the dword that holds element k - 1.
-        const int left = (int)p.k - (int)(c * (uint32_t)CHK);  // elements of this chunk inside the vector
+        const int left = (int)p.k - (int)((cbase + c) * (uint32_t)CHK);  // elements of this chunk inside the vector
 #pragma unroll
         for (int d = 0; d < CHK / 2; ++d) h[d] = left >= 2 * d + 2 ? h[d] : (left == 2 * d + 1 ? (h[d] & 0xFFFFu) : 0u);
       }
@@ -253,7 +264,7 @@ __global__ void __launch_bounds__(64 * NW)
     }
 #pragma unroll
     for (int r = 0; r < SI; ++r) {
-      const uint32_t e = (uint32_t)(r * ST + tid), g = e / NL, snl = e % NL;
+      const uint32_t e = (uint32_t)(r * ST + tid), g = gbase + e / NL, snl = e % NL;
       const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
       uint32_t sb[CPL];
       if constexpr (CPL == 2) {
@@ -281,7 +292,7 @@ __global__ void __launch_bounds__(64 * NW)
         bad = bad || !ok;
         ent[c] = (uint32_t)as_u16(s) | ((uint32_t)as_u16(neg_zero_times_scale(z, s)) << 16);
       }
-      if (g < p.tab_groups) *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent;
+      if (e / NL < p.tab_groups) *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent;
     }
   }
   {
@@ -303,7 +314,7 @@ __global__ void __launch_bounds__(64 * NW)
 
   // per-unit dequant constants of this lane's columns
   auto unit_consts = [&](uint32_t u, half2_t(&s2)[CPL], half2_t(&nzs2)[CPL], half2_t(&ss2)[CPL]) {
-    const uint32_t gi = (u * (uint32_t)LK + (uint32_t)kl) >> p.gshift;  // < tab_groups
+    const uint32_t gi = ((u * (uint32_t)LK + (uint32_t)kl) >> p.gshift) - gbase;  // < tab_groups
     const u32x4_t ent = *reinterpret_cast<const u32x4_t*>(s_tab + (gi * (uint32_t)NL + (uint32_t)nl) * 4u);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -348,9 +359,9 @@ __global__ void __launch_bounds__(64 * NW)
   // one unit: its rows are in X (in flight or landed); behind each step the rows Plan schedules go out, into Y (next
   // unit) and, once dead, back into X (the unit after that).  A unit past the end computes nothing and loads nothing real.
   auto process = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R]) {
-    const bool live = cur < p.units;  // wave-uniform
+    const bool live = cur < uend;  // wave-uniform
     half2_t s2[CPL], nzs2[CPL], ss2[CPL];
-    const uint32_t* const a_unit = s_act + cur * (uint32_t)(LK * UB * 16) + a_lane;
+    const uint32_t* const a_unit = s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16) + a_lane;
     if (live) unit_consts(cur, s2, nzs2, ss2);
     static_for<S>([&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
@@ -372,17 +383,17 @@ __global__ void __launch_bounds__(64 * NW)
     do {
       process(ra, rb);
       process(rb, ra);
-    } while (cur < p.units);
+    } while (cur < uend);
   } else {
     // some scale of the tile is too large for the subnormal form (or not finite): the spliced form, same W bit for bit.
     // Not a path real checkpoints take: plain loop, own loads, units w, w + NW, ...
-    for (uint32_t u = (uint32_t)wv; u < p.units; u += (uint32_t)NW) {
+    for (uint32_t u = ubeg + (uint32_t)wv; u < uend; u += (uint32_t)NW) {
       half2_t s2[CPL], nzs2[CPL], ss2[CPL];
       unit_consts(u, s2, nzs2, ss2);
       Row<CPL, NT> rs[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) rs[i].load(r_w, lane_off, u * unit_bytes + (uint32_t)i * row_bytes);
-      const uint32_t* const a_unit = s_act + u * (uint32_t)(LK * UB * 16) + a_lane;
+      const uint32_t* const a_unit = s_act + (u - ubeg) * (uint32_t)(LK * UB * 16) + a_lane;
       static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2); });
     }
   }
@@ -409,7 +420,33 @@ __global__ void __launch_bounds__(64 * NW)
 #pragma unroll
     for (int w = 0; w < NW * HS; ++w) sum += s_red[w * CN + tid];
     const uint32_t n_out = tile * CN + (uint32_t)tid;
-    if (n_out < p.n) p.out[n_out] = as_u16((_Float16)sum);
+    if constexpr (SPLIT) {
+      // One trip to the device coherence point, as in xbit_gemv_mfma.h: the partial sum goes into the element's 64-bit
+      // accumulator as a fixed-point integer (2^-28 units, biased positive) by ONE returning atomic whose upper bits count
+      // arrivals (bits 0-51 sum of (v + 2^47), 52-55 arrivals, 56-59 / 60-63 arrivals with a partial beyond +-2^19, Inf
+      // or NaN); integer addition is associative, so the result does not depend on the arrival order.  The thread that
+      // completes the count converts, stores and clears the slot.  Contract: include/xbitops_hip.h (split_k).
+      if (n_out < p.n) {
+        unsigned long long* slot = p.acc + (size_t)tile * (size_t)CN + (size_t)tid;
+        const bool fin = __builtin_fabsf(sum) < 524288.0f;
+        const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;
+        const unsigned long long pos = (!fin && !(sum < 0.f)) ? (1ull << 56) : 0ull;
+        const unsigned long long neg = (!fin && !(sum > 0.f)) ? (1ull << 60) : 0ull;
+        const unsigned long long add = (unsigned long long)(v + (1ll << 47)) + (1ull << 52) + pos + neg;
+        const unsigned long long old = __hip_atomic_fetch_add(slot, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((old >> 52) & 15ull) + 1ull == p.splits) {
+          const unsigned long long tot = old + add;
+          const long long fixed = (long long)(tot & ((1ull << 52) - 1ull)) - (long long)p.splits * (1ll << 47);
+          float y = (float)fixed * (1.0f / 268435456.0f);
+          const bool any_pos = ((tot >> 56) & 15ull) != 0, any_neg = (tot >> 60) != 0;
+          if (any_pos || any_neg) y = (any_pos && any_neg) ? __builtin_nanf("") : (any_pos ? __builtin_inff() : -__builtin_inff());
+          p.out[n_out] = as_u16((_Float16)y);
+          __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    } else {
+      if (n_out < p.n) p.out[n_out] = as_u16((_Float16)sum);
+    }
   }
   if constexpr (STAMP) {
     stamp[5] = __builtin_amdgcn_s_memrealtime();
@@ -440,26 +477,34 @@ constexpr int dyn_ub() {
   return BITS == 2 ? 2 : 1;  // >= 3 row loads per unit
 }
 
-template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0>
+template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false>
 int launch_dyn_one(const DynParams& p, hipStream_t stream) {
   constexpr int UB = dyn_ub<BITS>();
-  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS>;
+  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS, SPLIT>;
   DynParams q = p;
   void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias,
-                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.trace};
-  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles), dim3(64 * kDynWaves), dyn_lds_bytes(p, NL, kDynWaves, CPL), stream, args);
+                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.trace};
+  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u)), dim3(64 * kDynWaves),
+                            dyn_lds_bytes(p, NL, kDynWaves, CPL), stream, args);
 }
 
 template <int BITS, int CPL, int NL, bool NT>
 int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool stamped) {
 #if XBIT_TUNING
   if (stamped) {
-    if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 2>(p, stream);
+    if (rounds <= 2u && p.splits <= 1u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 2>(p, stream);
     return kDynNotEligible;
   }
 #else
   (void)stamped;
 #endif
+  if (p.splits > 1u) {  // split-K: 32- and 64-column tiles, K ranges of up to 4096 (2 rounds) or 8192 (4 rounds)
+    if constexpr (NL == 16 && CPL != 3) {
+      if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true>(p, stream);
+      if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, true>(p, stream);
+    }
+    return kDynNotEligible;
+  }
   // one build per count of staging rounds (2: K <= 4096 at group 128; 3: K = 5120; 4: K <= 8192; 8: up to 16384).  A build
   // that skips unneeded rounds at run time instead took 0.9 us longer per launch (profiles/r03/lab_9.txt, lab_10.txt).
   if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2>(p, stream);
@@ -472,8 +517,10 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 // One-row GEMV through the staged-operand kernel, or kDynNotEligible.  `cpl` / `nl`: tile shape (16 * cpl columns, or
 // nl = 8: 8 * cpl); the caller picks them.  Eligible: one activation row (any k), group size a power-of-two multiple
 // of 32 * UB, 4-byte aligned tensors, staged operands within kDynMaxLds and 8 staging rounds, every byte offset below 2^31.
+// `splits` >= 2 with `acc` (zeroed accumulators, one per output element of whole tiles): K is cut into that many ranges.
 template <int BITS>
-int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace) {
+int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
+                    unsigned long long* acc = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
   if (g.m != 1u || g.groupsize % (32u * UB) != 0u) return kDynNotEligible;
   if (((uintptr_t)g.a | (uintptr_t)g.qweight | (uintptr_t)g.scales | (uintptr_t)g.qzeros) % 4u != 0u) return kDynNotEligible;  // dword buffer loads
@@ -498,12 +545,21 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   const uint32_t lk = 64u / (uint32_t)nl, kblocks = (g.k + 31u) / 32u;
   p.tiles = (g.n + (uint32_t)(nl * cpl) - 1u) / (uint32_t)(nl * cpl);
   p.units = (kblocks + lk * UB - 1u) / (lk * UB);
-  p.act_bytes = p.units * lk * UB * 64u;
-  p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
-  if (p.tab_groups < p.groups) p.tab_groups = p.groups;
+  p.splits = splits >= 2u && acc != nullptr ? splits : 1u;
+  p.ups = (p.units + p.splits - 1u) / p.splits;
+  p.acc = acc;
+  if (p.splits > 1u && (p.ups < 8u || (p.splits - 1u) * p.ups >= p.units)) return kDynNotEligible;  // every range holds a unit for every wave
+  p.act_bytes = p.ups * lk * UB * 64u;
+  // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
+  // launches cover at least `groups` rows so that the zero rows past the last group exist
+  p.tab_groups = ((p.ups * lk - 1u + ((1u << p.gshift) - 1u)) >> p.gshift) + 1u;
+  if (p.splits == 1u) {
+    p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
+    if (p.tab_groups < p.groups) p.tab_groups = p.groups;
+  }
   if (dyn_lds_bytes(p, nl, kDynWaves, cpl) > kDynMaxLds) return kDynNotEligible;
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
-  if (((uint64_t)p.units + 3u * kDynWaves) * unit_bytes >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
+  if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
   constexpr uint32_t st = 64u * kDynStagers;
   const uint32_t chunks = p.act_bytes / (uint32_t)(Unpack<BITS>::kChunkK * 2);
   const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;

@@ -3,8 +3,9 @@
 
 namespace xbit {
 
-int launch_gemv_dyn_b4(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace) {
-  return dyn::launch_dyn_bits<4>(p, stream, cpl, nl, nt, stamped, trace);
+int launch_gemv_dyn_b4(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
+                       unsigned long long* acc) {
+  return dyn::launch_dyn_bits<4>(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
 }
 
 }  // namespace xbit

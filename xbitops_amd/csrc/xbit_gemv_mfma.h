@@ -1210,22 +1210,40 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
     {
       SplitPlan plan = plan_split(p, UBMAX, opts.split, BITS);
+      // 2- and 3-bit at K <= 8192 with >= 3072 columns: the unsplit staged-operand kernel on 16-column tiles beats every
+      // split (8192x3584 w2 5.5 against 6.1 us, 8192x4096 w3 6.0 against 6.5; sweep_split_dyn.txt)
+      if (opts.split == 0 && p.m == 1u && BITS <= 3 && kblocks <= 256u && p.n >= 3072u && variant <= 0) plan.splits = 0;
       if (variant == 206 && plan.splits >= 2) {  // measurement: 32-column tiles read as 8 lanes x 16 B (NL = 8), split as planned
         const uint32_t tiles = (p.n + 31u) / 32u;
         const size_t slots = (size_t)tiles * 32u;
         GemvWorkspace ws;
         if (p.m == 1 && gemv_workspace(stream, slots, opts, &ws)) return launch_split_rows<BITS, 2, 4, 8, 8>(p, stream, plan.splits, ws);
       }
-      if ((variant == 202 || variant == 205) && plan.splits >= 2) {  // sweep hook (tuning builds): force the tile width
-        plan.cpl = variant == 202 ? 2 : 4;
-      } else if (variant > 0 && variant != 398) {
+      if ((variant == 202 || variant == 205 || variant == 332 || variant == 334) && plan.splits >= 2) {  // sweep hooks (tuning builds): force the tile width
+        plan.cpl = (variant == 202 || variant == 332) ? 2 : 4;
+      } else if (variant > 0 && variant != 398 && variant != 330) {
         plan.splits = 0;  // another measurement variant was asked for
       }
       if (plan.splits >= 2) {
         const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
         const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
         GemvWorkspace ws;
-        if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
+        if (gemv_workspace(stream, slots, opts, &ws)) {
+          // one row: the same plan through the staged-operand kernel's split-K build (tuning builds: variants 330 / 332 /
+          // 334 force it with the planned / 32-column / 64-column tiles, 398 keeps this file's kernel)
+          // Production rule (chain periods, profiles/r03/sweep_split_dyn.txt): the staged-operand build wins where every one
+          // of its eight waves gets the same number of units or many of them (units per K range == 16 or >= 24: 8192x3584
+          // w4 6.5 -> 6.1 us, 14336x4096 8.8 -> 8.1, 28672x4096 14.0 -> 13.1, 16384x1024 5.7 -> 4.9) and loses on the
+          // ranges of 15-18 units that the plans for K = 11008 / 13824 use (11008x4096 7.8 against 8.6).
+          const uint32_t dyn_units = (kblocks + (BITS == 2 ? 8u : 4u) - 1u) / (BITS == 2 ? 8u : 4u), dyn_ups = (dyn_units + plan.splits - 1u) / plan.splits;
+          const bool by_rule = dyn_ups == 16u || dyn_ups >= 24u;
+          const bool dyn_split = XBIT_TUNING ? (variant == 330 || variant == 332 || variant == 334 || (variant <= 0 && by_rule)) : by_rule;
+          if (p.m == 1u && dyn_split) {
+            const int st = launch_gemv_dyn(p, BITS, stream, plan.cpl, 16, true, false, nullptr, plan.splits, ws.acc);
+            if (st != kGemvDynNotEligible) return st;
+          }
+          return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
+        }
       }
     }
     {
@@ -1237,7 +1255,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       const bool small_n = cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128;
       const bool wide = (BITS == 4 || BITS == 8) && p.n >= 25600u && kblocks / UBMAX >= 32;
       const uint32_t dyn_tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
-      const bool wins = small_n ? BITS >= 3 : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
+      const bool wins = small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
       if ((wins && !wide) || (XBIT_TUNING && variant >= 300)) {
         const int st = try_dyn(cpl, small_n);
         if (st != kGemvDynNotEligible) return st;

@@ -137,7 +137,9 @@ int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
 // One activation row through the staged-operand kernel (xbit_gemv_dyn.h): tiles of 16 * cpl columns (nl = 16) or 16 columns
 // (nl = 8, cpl = 2).  Returns kGemvDynNotEligible when the shape is not for that kernel (the caller launches another).
 constexpr int kGemvDynNotEligible = 1 << 30;
-int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace);  // xbit_gemv_dyn.hip
+// splits >= 2 with acc (zeroed 64-bit accumulators, one per output element of whole tiles): K cut into that many ranges
+int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
+                    unsigned long long* acc = nullptr);  // xbit_gemv_dyn.hip
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);     // xbit_gidx.hip
 int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);
 
