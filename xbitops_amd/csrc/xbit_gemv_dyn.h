@@ -100,6 +100,7 @@ struct DynParams {
   uint32_t act_bytes;       // LDS bytes of the staged activation vector: (units of one K range) * LK * UB * 64
   uint32_t splits, ups;     // split-K builds: K ranges per tile and units per range (whole-K: 1, units)
   unsigned long long* acc;  // split-K builds: one 64-bit accumulator per output element, zero between launches
+  const int32_t* g_idx;     // act-order builds: the group of row k (k entries; values are clamped to [0, groups))
   uint64_t* trace;          // stamped build only
 };
 
@@ -116,14 +117,18 @@ struct DynParams {
 //   SPLIT  split-K: workgroup (tile, split) sums units [split * ups, (split + 1) * ups) only and stages only that range's
 //          activations and groups; the partial sums meet in per-element 64-bit fixed-point accumulators exactly as in
 //          xbit_gemv_mfma.h (one returning atomic per element and workgroup; the last arriver converts, stores and clears)
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false>
+//   GIDX   act-order ("desc_act", quant_cuda_kernel.cu:257-336 in the reference): the group of row k is g_idx[k].  The ids
+//          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
+//          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
+//          column more than the contiguous build, no change to the weight stream.
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false, bool GIDX = false>
 __global__ void __launch_bounds__(64 * NW)
     gemv_dyn_kernel(const uint32_t* qweight, uint32_t n, uint32_t tiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales,
                     const uint32_t* qzeros, uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t tab_groups, uint32_t gshift,
-                    uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, uint64_t* trace) {
+                    uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, const int32_t* g_idx, uint64_t* trace) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, tab_groups, gshift, act_bytes, splits, ups, split_acc, trace};
+  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
@@ -136,11 +141,15 @@ __global__ void __launch_bounds__(64 * NW)
   constexpr uint32_t kOob = 0x80000000u;
   static_assert(NL == 16 || NL == 8, "lanes along N");
   static_assert(STW >= 1 && STW <= NW, "staging waves");
+  static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  // LDS: [activations: act_bytes][table: tab_groups * NL lanes * 16 B][reduction: NW * HS * CN floats][bad flags: 8 dwords]
+  // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
+  //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * CN floats][bad flags: 8 dwords]
   uint32_t* const s_act = s_dyn;
-  uint32_t* const s_tab = s_dyn + p.act_bytes / 4u;
-  float* const s_red = reinterpret_cast<float*>(s_tab + p.tab_groups * (uint32_t)(NL * 4));
+  uint32_t* const s_gid = s_act + p.act_bytes / 4u;
+  uint32_t* const s_tab = s_gid + (GIDX ? p.act_bytes / 4u : 0u);
+  uint32_t* const s_tab_plain = s_tab + (GIDX ? p.tab_groups * (uint32_t)(NL * 4) : 0u);
+  float* const s_red = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
   uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * CN + 3) & ~3));
 
   const int tid = threadIdx.x, lane = tid & 63, kl = lane / NL, nl = lane % NL;
@@ -168,7 +177,17 @@ __global__ void __launch_bounds__(64 * NW)
   // return zeros, no traffic); lane slots past the last column read some other column's values, which are never stored.
   u32x4_t act_raw[SI][CPT];
   uint32_t s_raw[SI][2], z_raw[SI][2];
+  u32x4_t g_raw[GIDX ? SI : 1][2];  // act-order: the ids of 8 consecutive rows per round
+  const rsrc_t r_g = make_rsrc(GIDX ? static_cast<const void*>(p.g_idx) : static_cast<const void*>(p.a), GIDX ? p.k * 4u : 0u);
   if (stager) {
+    if constexpr (GIDX) {
+#pragma unroll
+      for (int r = 0; r < SI; ++r) {
+        const uint32_t c = (uint32_t)(r * ST + tid);
+        g_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u, 0, 0);  // rows past k read id 0: their activations are 0
+        g_raw[r][1] = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u + 16u, 0, 0);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < SI; ++r) {
       const uint32_t c = (uint32_t)(r * ST + tid);
@@ -283,16 +302,40 @@ __global__ void __launch_bounds__(64 * NW)
       if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) zwin = z_raw[r][0] >> zsh;
       else zwin = __builtin_amdgcn_alignbit(z_raw[r][1], z_raw[r][0], zsh);
       u32x4_t ent = {0u, 0u, 0u, 0u};  // (scale | -(zero + bias) * scale << 16) per column
+      u32x4_t ent_sub = {0u, 0u, 0u, 0u};  // act-order: the scale pre-multiplied for the subnormal form (a pair mixes two groups)
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const _Float16 s = as_h((uint16_t)sb[c]);
         const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + p.bias;
         bool ok;
-        (void)sub_scale<BITS>(s, ok);
+        const _Float16 ssub = sub_scale<BITS>(s, ok);
         bad = bad || !ok;
-        ent[c] = (uint32_t)as_u16(s) | ((uint32_t)as_u16(neg_zero_times_scale(z, s)) << 16);
+        const uint32_t nz = (uint32_t)as_u16(neg_zero_times_scale(z, s)) << 16;
+        ent[c] = (uint32_t)as_u16(s) | nz;
+        ent_sub[c] = (uint32_t)as_u16(ssub) | nz;
       }
-      if (e / NL < p.tab_groups) *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent;
+      if (e / NL < p.tab_groups) {
+        if constexpr (GIDX) {
+          *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent_sub;
+          *reinterpret_cast<u32x4_t*>(s_tab_plain + e * 4u) = ent;
+        } else {
+          *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent;
+        }
+      }
+    }
+    if constexpr (GIDX) {
+#pragma unroll
+      for (int r = 0; r < SI; ++r) {
+        const uint32_t c = (uint32_t)(r * ST + tid);
+        const uint32_t top = p.groups - 1u;
+        u32x4_t o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const uint32_t lo = d < 2 ? g_raw[r][0][2 * d] : g_raw[r][1][2 * d - 4], hi = d < 2 ? g_raw[r][0][2 * d + 1] : g_raw[r][1][2 * d - 3];
+          o[d] = (lo < top ? lo : top) | ((hi < top ? hi : top) << 16);  // out-of-range (or negative) ids are clamped, never followed
+        }
+        if (c * 16u < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_gid + c * 4u) = o;
+      }
     }
   }
   {
@@ -325,9 +368,10 @@ __global__ void __launch_bounds__(64 * NW)
       ss2[c] = (s2[c] * splat((_Float16)(float)(1 << 8))) * splat((_Float16)(float)(1 << (L - 8)));
     }
   };
-  // one MFMA step: octet `oct` of k-block `j` of the unit whose rows are in X
+  // one MFMA step: octet `oct` of k-block `j` of the unit whose rows are in X.  `gq`: act-order only - the 32 group ids of
+  // each of the lane's k-blocks, two per dword.
   auto step = [&](const Row<CPL, NT>(&X)[R], const uint32_t* a_unit, auto s_c, auto fast_c, const half2_t(&s2)[CPL], const half2_t(&nzs2)[CPL],
-                  const half2_t(&ss2)[CPL]) {
+                  const half2_t(&ss2)[CPL], const uint32_t(&gq)[GIDX ? UB : 1][16]) {
     constexpr int s = decltype(s_c)::value, j = s / 4, oct = s % 4;
     constexpr bool FAST = decltype(fast_c)::value;
     const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + j * 16 + 4 * oct);
@@ -340,20 +384,52 @@ __global__ void __launch_bounds__(64 * NW)
     u32x4_t braw[CPL];
     static_for<4>([&](auto e_c) {
       constexpr int e = decltype(e_c)::value, pr = 4 * oct + e;
+      half2_t ps[CPL], pnz[CPL];  // this pair's scale (pre-multiplied on the fast path) and -zero*scale, low half = lower k
+      if constexpr (GIDX) {
+        constexpr int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
+        const uint32_t id_lo = (gq[j][klo >> 1] >> (16 * (klo & 1))) & 0xFFFFu, id_hi = (gq[j][khi >> 1] >> (16 * (khi & 1))) & 0xFFFFu;
+        const uint32_t* const tab = FAST ? s_tab : s_tab_plain;
+        const u32x4_t elo = *reinterpret_cast<const u32x4_t*>(tab + (id_lo * (uint32_t)NL + (uint32_t)nl) * 4u);
+        const u32x4_t ehi = *reinterpret_cast<const u32x4_t*>(tab + (id_hi * (uint32_t)NL + (uint32_t)nl) * 4u);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          ps[c] = as_h2(__builtin_amdgcn_perm(ehi[c], elo[c], 0x05040100u));
+          pnz[c] = as_h2(__builtin_amdgcn_perm(ehi[c], elo[c], 0x07060302u));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          ps[c] = FAST ? ss2[c] : s2[c];
+          pnz[c] = nzs2[c];
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         if constexpr (FAST) {
           const uint32_t q = Unpack<BITS>::template sub_pair<pr>(wc[c], sub_mask);
-          braw[c][e] = as_u32(__builtin_elementwise_fma(as_h2(q), ss2[c], nzs2[c]));
+          braw[c][e] = as_u32(__builtin_elementwise_fma(as_h2(q), ps[c], pnz[c]));
         } else {
           const uint32_t q = Unpack<BITS>::template pair<pr>(wc[c], uk);
-          braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(q, s2[c], nzs2[c]));
+          braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(q, ps[c], pnz[c]));
         }
       }
     });
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
       acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+  };
+  // act-order: the ids of the lane's k-blocks of unit u (64 bytes per k-block)
+  auto unit_ids = [&](uint32_t u, uint32_t(&gq)[GIDX ? UB : 1][16]) {
+    if constexpr (GIDX) {
+      const uint32_t* const g_unit = s_gid + ((u - ubeg) * (uint32_t)LK + (uint32_t)kl) * (uint32_t)(UB * 16);
+#pragma unroll
+      for (int j = 0; j < UB; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(g_unit + j * 16 + 4 * q);
+          gq[j][4 * q + 0] = v.x; gq[j][4 * q + 1] = v.y; gq[j][4 * q + 2] = v.z; gq[j][4 * q + 3] = v.w;
+        }
+    }
   };
 
   // one unit: its rows are in X (in flight or landed); behind each step the rows Plan schedules go out, into Y (next
@@ -362,10 +438,14 @@ __global__ void __launch_bounds__(64 * NW)
     const bool live = cur < uend;  // wave-uniform
     half2_t s2[CPL], nzs2[CPL], ss2[CPL];
     const uint32_t* const a_unit = s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16) + a_lane;
-    if (live) unit_consts(cur, s2, nzs2, ss2);
+    uint32_t gq[GIDX ? UB : 1][16];
+    if (live) {
+      if constexpr (GIDX) unit_ids(cur, gq);
+      else unit_consts(cur, s2, nzs2, ss2);
+    }
     static_for<S>([&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
-      if (live) step(X, a_unit, s_c, std::true_type{}, s2, nzs2, ss2);
+      if (live) step(X, a_unit, s_c, std::true_type{}, s2, nzs2, ss2, gq);
       __builtin_amdgcn_sched_barrier(0);
       constexpr int from = P::need(s) + LA, to = P::need(s + 1) + LA;
       // a row of the unit after next reuses a register of this unit: it must be dead by now
@@ -389,12 +469,14 @@ __global__ void __launch_bounds__(64 * NW)
     // Not a path real checkpoints take: plain loop, own loads, units w, w + NW, ...
     for (uint32_t u = ubeg + (uint32_t)wv; u < uend; u += (uint32_t)NW) {
       half2_t s2[CPL], nzs2[CPL], ss2[CPL];
-      unit_consts(u, s2, nzs2, ss2);
+      uint32_t gq[GIDX ? UB : 1][16];
+      if constexpr (GIDX) unit_ids(u, gq);
+      else unit_consts(u, s2, nzs2, ss2);
       Row<CPL, NT> rs[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) rs[i].load(r_w, lane_off, u * unit_bytes + (uint32_t)i * row_bytes);
       const uint32_t* const a_unit = s_act + (u - ubeg) * (uint32_t)(LK * UB * 16) + a_lane;
-      static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2); });
+      static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2, gq); });
     }
   }
   if constexpr (STAMP) {
@@ -465,7 +547,8 @@ __global__ void __launch_bounds__(64 * NW)
 // LDS bytes of one workgroup (dynamic)
 inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl) {
   const int hs = 16 / nl, cn = nl * cpl;
-  return (size_t)p.act_bytes + (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * cn + 3) & ~3) * 4u + 32u;
+  const size_t twice = p.g_idx != nullptr ? 2u : 1u;  // act-order: group ids beside the activations, a second table for the spliced form
+  return twice * (size_t)p.act_bytes + twice * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * cn + 3) & ~3) * 4u + 32u;
 }
 
 constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
@@ -477,13 +560,13 @@ constexpr int dyn_ub() {
   return BITS == 2 ? 2 : 1;  // >= 3 row loads per unit
 }
 
-template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false>
+template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false>
 int launch_dyn_one(const DynParams& p, hipStream_t stream) {
   constexpr int UB = dyn_ub<BITS>();
-  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS, SPLIT>;
+  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS, SPLIT, GIDX>;
   DynParams q = p;
   void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias,
-                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.trace};
+                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.g_idx, &q.trace};
   return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u)), dim3(64 * kDynWaves),
                             dyn_lds_bytes(p, NL, kDynWaves, CPL), stream, args);
 }
@@ -498,6 +581,13 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #else
   (void)stamped;
 #endif
+  if (p.g_idx != nullptr) {  // act-order: 48-column tiles, K up to 4096 (2 rounds) or 8192 (4 rounds)
+    if constexpr (NL == 16 && CPL == 3) {
+      if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true>(p, stream);
+      if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, true>(p, stream);
+    }
+    return kDynNotEligible;
+  }
   if (p.splits > 1u) {  // split-K: 32- and 64-column tiles, K ranges of up to 4096 (2 rounds) or 8192 (4 rounds)
     if constexpr (NL == 16 && CPL != 3) {
       if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true>(p, stream);
@@ -520,11 +610,15 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 // `splits` >= 2 with `acc` (zeroed accumulators, one per output element of whole tiles): K is cut into that many ranges.
 template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
-                    unsigned long long* acc = nullptr) {
+                    unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g.m != 1u || g.groupsize % (32u * UB) != 0u) return kDynNotEligible;
+  if (g_idx != nullptr) {  // act-order: any ids, the "group size" only sizes nothing here; 48-column tiles, whole K
+    if (g.m != 1u || splits > 1u || nl != 16 || cpl != 3 || g.groups > 65535u || (uintptr_t)g_idx % 4u != 0u) return kDynNotEligible;
+  } else if (g.m != 1u || g.groupsize % (32u * UB) != 0u) {
+    return kDynNotEligible;
+  }
   if (((uintptr_t)g.a | (uintptr_t)g.qweight | (uintptr_t)g.scales | (uintptr_t)g.qzeros) % 4u != 0u) return kDynNotEligible;  // dword buffer loads
-  const uint32_t d = g.groupsize / (32u * UB);
+  const uint32_t d = g_idx != nullptr ? 1u : g.groupsize / (32u * UB);
   if ((d & (d - 1u)) != 0u) return kDynNotEligible;
   if (nl != 16 && !(nl == 8 && cpl == 2)) return kDynNotEligible;
   DynParams p;
@@ -540,6 +634,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   p.zw = g.zw;
   p.bias = g.bias;
   p.trace = trace;
+  p.g_idx = g_idx;
   p.gshift = 0;
   while ((1u << p.gshift) < d) ++p.gshift;
   const uint32_t lk = 64u / (uint32_t)nl, kblocks = (g.k + 31u) / 32u;
@@ -557,13 +652,15 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
     p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
     if (p.tab_groups < p.groups) p.tab_groups = p.groups;
   }
+  if (g_idx != nullptr) p.tab_groups = p.groups;  // every group, whatever K
   if (dyn_lds_bytes(p, nl, kDynWaves, cpl) > kDynMaxLds) return kDynNotEligible;
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
   if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
   constexpr uint32_t st = 64u * kDynStagers;
   const uint32_t chunks = p.act_bytes / (uint32_t)(Unpack<BITS>::kChunkK * 2);
   const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
-  const uint32_t rounds = r_act > r_tab ? r_act : r_tab;
+  const uint32_t r_gid = g_idx != nullptr ? (p.act_bytes / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round
+  const uint32_t rounds = r_act > r_tab ? (r_act > r_gid ? r_act : r_gid) : (r_tab > r_gid ? r_tab : r_gid);
 #define XBIT_DYN(CPL_, NL_)                                                                      \
   return nt ? launch_dyn_si<BITS, CPL_, NL_, true>(p, stream, rounds, stamped)                   \
             : launch_dyn_si<BITS, CPL_, NL_, XBIT_TUNING ? false : true>(p, stream, rounds, stamped)

@@ -5,30 +5,30 @@
 namespace xbit {
 
 int launch_gemv_dyn_b2(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 int launch_gemv_dyn_b3(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 int launch_gemv_dyn_b4(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 int launch_gemv_dyn_b5(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 int launch_gemv_dyn_b6(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 int launch_gemv_dyn_b7(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 int launch_gemv_dyn_b8(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc);
+                       unsigned long long* acc, const int32_t* g_idx);
 
 int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                    unsigned long long* acc) {
+                    unsigned long long* acc, const int32_t* g_idx) {
   switch (bits) {
-    case 2: return launch_gemv_dyn_b2(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
-    case 3: return launch_gemv_dyn_b3(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
-    case 4: return launch_gemv_dyn_b4(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
-    case 5: return launch_gemv_dyn_b5(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
-    case 6: return launch_gemv_dyn_b6(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
-    case 7: return launch_gemv_dyn_b7(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
-    case 8: return launch_gemv_dyn_b8(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
+    case 2: return launch_gemv_dyn_b2(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
+    case 3: return launch_gemv_dyn_b3(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
+    case 4: return launch_gemv_dyn_b4(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
+    case 5: return launch_gemv_dyn_b5(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
+    case 6: return launch_gemv_dyn_b6(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
+    case 7: return launch_gemv_dyn_b7(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
+    case 8: return launch_gemv_dyn_b8(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
     default: return XBIT_ERR_BITS;
   }
 }

@@ -4,8 +4,8 @@
 namespace xbit {
 
 int launch_gemv_dyn_b8(const GemvParams& p, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits,
-                       unsigned long long* acc) {
-  return dyn::launch_dyn_bits<8>(p, stream, cpl, nl, nt, stamped, trace, splits, acc);
+                       unsigned long long* acc, const int32_t* g_idx) {
+  return dyn::launch_dyn_bits<8>(p, stream, cpl, nl, nt, stamped, trace, splits, acc, g_idx);
 }
 
 }  // namespace xbit

@@ -157,6 +157,31 @@ int launch_gemv_gidx_bits(const GemvGidxParams& p, hipStream_t stream) {
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
   if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
   if (p.m > 65535u) return XBIT_ERR_SHAPE;
+  // Up to 16 rows: the act-order build of the staged-operand kernel (xbit_gemv_dyn.h), one launch per row - the weight
+  // stream and the arithmetic of the contiguous-group kernel plus a per-pair table lookup (4096x11008 w4: 29.8 -> see
+  // profiles/r03/gidx_after.txt).  More rows, very many groups or a K beyond its staging: the kernels of this file.
+  if (p.m <= 16u) {
+    GemvParams q{};
+    q.qweight = p.qweight;
+    q.scales = p.scales;
+    q.qzeros = p.qzeros;
+    q.m = 1;
+    q.k = p.k;
+    q.n = p.n;
+    q.groupsize = 128;  // not used by the act-order build
+    q.kw = p.kw;
+    q.groups = p.groups;
+    q.zw = p.zw;
+    q.bias = p.bias;
+    int st = kGemvDynNotEligible;
+    for (uint32_t r = 0; r < p.m; ++r) {
+      q.a = p.a + (size_t)r * p.k;
+      q.out = p.out + (size_t)r * p.n;
+      st = launch_gemv_dyn(q, bits, stream, 3, 16, true, false, nullptr, 1, nullptr, p.g_idx);
+      if (st != XBIT_OK) break;  // not eligible (decided before anything was launched: r == 0) or a launch error
+    }
+    if (st != kGemvDynNotEligible) return st;
+  }
   const bool fast = p.groups <= kGxMaxGroups && p.n % 4u == 0 && ((uintptr_t)p.qweight % 16 == 0) &&
                     (uint64_t)p.kw * p.n < (1ull << 32) && (p.n + kGxCols - 1) / kGxCols <= 0x7FFFFFFFu;
   if (fast) {

@@ -139,7 +139,7 @@ int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
 constexpr int kGemvDynNotEligible = 1 << 30;
 // splits >= 2 with acc (zeroed 64-bit accumulators, one per output element of whole tiles): K cut into that many ranges
 int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
-                    unsigned long long* acc = nullptr);  // xbit_gemv_dyn.hip
+                    unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr);  // xbit_gemv_dyn.hip; g_idx: act-order (group of row k), 48-column tiles, whole K
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);     // xbit_gidx.hip
 int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);
 
