@@ -45,8 +45,8 @@
  *     per buffer; xbit_gemv_workspace_bytes says how much), or
  *   - the library's: one 2 MiB buffer per (device, stream) for eager launches (launches on a stream
  *     run in order, so they can share it) and, for a launch recorded by a stream capture, a private
- *     range of a per-device pool that is never handed out again - a captured graph may replay on any
- *     stream, concurrently with anything, so it cannot share.  Nothing is allocated inside a capture:
+ *     range of a per-device pool that is not handed out again until xbit_workspace_release() - a captured
+ *     graph may replay on any stream, concurrently with anything, so it cannot share.  Nothing is allocated inside a capture:
  *     the pool is created by the first eager split-K launch on the device or by xbit_workspace_reset().
  *     If no scratch can be had (no pool yet, allocation failure, pool exhausted) the launch simply
  *     is not split; the result differs from the split one only in the fp32 summation order.
@@ -138,6 +138,18 @@ uint64_t xbit_gemv_workspace_bytes(uint32_t m, uint32_t n);
  * the current device (synchronises the device; not to be called while a stream is being captured).
  * Returns 0 or a positive hipError_t. */
 int xbit_workspace_reset(void);
+
+/* Hand the whole capture pool of the current device out again (synchronises the device and re-zeroes it first).
+ * A captured split-K launch keeps its range for the life of the process otherwise (the pool is 8 MiB: about 250
+ * captured launches of a 4096-column layer); a host that re-captures its graphs - per batch size, per sequence
+ * bucket - calls this once the old graphs are destroyed.  Graphs captured BEFORE the call must not be replayed
+ * after it: their ranges may now belong to another launch.  Returns 0 or a positive hipError_t. */
+int xbit_workspace_release(void);
+
+/* Bytes of the current device's capture pool that are still free (0 before the pool exists).  A capture that
+ * needs more than this runs its launch unsplit - same result up to the fp32 summation order, slower on long-K
+ * layers - so a host can check before capturing instead of finding out from the timing. */
+uint64_t xbit_workspace_capture_bytes_free(void);
 
 /* Act-order ("desc_act") checkpoints: the group of row k is g_idx[k] instead of k / groupsize.
  * Counterpart of the reference's vecquant4matmul_g_cuda / VecQuant4MatMulKernel_G

@@ -117,11 +117,24 @@ def _run_rows(lib, p, bias, dev):
 
 
 @pytest.mark.parametrize("bits", range(2, 9))
-def test_column_kernel_shapes(bits, cuda_device):
-    """What no fast kernel takes - group sizes that are not a multiple of 32 (16, 48, 80, 1000: a group may begin anywhere
-    inside a k-block), ragged K with several rows, odd tile edges - runs the coalesced column kernel: exact W, fp32 sums."""
+def test_odd_group_sizes_one_to_four_rows(bits, cuda_device):
+    """Group sizes that are not a multiple of 32 (16, 48, 80, 1000, 17: a group may begin anywhere inside a k-block), one
+    to four rows: the staged-operand kernel's by-id build with the ids computed as k / groupsize (ragged K included at one
+    row; K = 4096 at group 16 is the largest table it takes: 256 groups)."""
     lib = _lib.load()
-    for k, n, g, m in [(4096, 1024, 48, 1), (2048, 130, 16, 1), (7167, 512, 80, 1), (1000, 66, 1000, 3), (333, 64, 17, 5), (7167, 1024, 128, 4), (96, 2, 16, 2)]:
+    for k, n, g, m in [(4096, 1024, 48, 1), (2048, 130, 16, 1), (7167, 512, 80, 1), (1000, 66, 1000, 3), (4096, 96, 16, 4), (96, 2, 16, 2),
+                       (1024, 4100, 17, 1), (8192, 48, 48, 2)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_column_kernel_shapes(bits, cuda_device):
+    """What no fast kernel takes - more than four rows of an odd group size, ragged K with several rows, more groups than
+    the by-id table holds - runs the coalesced column kernel: exact W, fp32 sums."""
+    lib = _lib.load()
+    for k, n, g, m in [(333, 64, 17, 5), (7167, 1024, 128, 4), (2048, 256, 48, 9), (1000, 66, 1000, 6), (8192, 130, 16, 1), (1001, 70, 80, 2)]:
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m))
@@ -165,3 +178,29 @@ def test_split_k_build_vs_oracle(bits, variant, cuda_device):
         y = _run(lib, p, 1, cuda_device, variant)
         _close(y, _ref(p, 1), (bits, variant, k, n, g))
         assert np.array_equal(_bits(y), _bits(_run(lib, p, 1, cuda_device, variant)))  # arrival order does not matter: integer sums
+
+
+def _run_m(lib, p, bias, dev, variant=-1):
+    a, qw, sc, qz = (torch.from_numpy(x).to(dev) for x in (p.act, p.qweight, p.scales, p.qzeros))
+    out = torch.full((p.m, p.n), float("nan"), dtype=torch.float16, device=dev)
+    st = lib.xbit_gemv_f16_ex(out.data_ptr(), a.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), p.bits, p.groupsize, p.m, p.k, p.n, bias,
+                              torch.cuda.current_stream().cuda_stream, _lib.GemvOptions(variant=variant))
+    _lib.check(st, "xbit_gemv_f16_ex")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+@pytest.mark.parametrize("variant", [302, 303, 304])
+def test_two_to_four_rows_forced_tile_shapes(bits, variant, cuda_device):
+    """The 4-row build (rows 2..4 per launch): every tile width, two staging-round counts, an edge tile; each row equals the
+    oracle and does not depend on the rows beside it."""
+    lib = _lib.load_tuning()
+    for k, n, g, m in [(4096, 1030, 128, 4), (2048, 2048, 64, 2), (8192, 344, 128, 3)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 5 + variant + m)
+        y = _run_m(lib, p, 1, cuda_device, variant)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, variant, k, n, g, m))
+        p1 = synth.Problem(k, n, bits, g, 1, p.qweight, p.scales, p.qzeros, p.act[m - 1:m])
+        y1 = _run_m(lib, p1, 1, cuda_device, variant)
+        ulp = np.abs(_bits(y[m - 1]).astype(np.int32) - _bits(y1[0]).astype(np.int32))
+        assert (ulp <= 1).all() or np.abs(y[m - 1].astype(np.float32) - y1[0].astype(np.float32)).max() <= 3e-5

@@ -689,6 +689,52 @@ def test_split_k_shape_inside_graph_capture(cuda_device):
         assert_gemv_close(y.cpu().numpy(), y_ref, "graph replay, warm=%s" % warm)
 
 
+def test_capture_pool_release_hands_the_ranges_out_again(cuda_device):
+    """Every captured split-K launch keeps a private range of the per-device pool; xbit_workspace_capture_bytes_free
+    reports what is left, xbit_workspace_release hands everything out again, and a graph captured afterwards still
+    gives the oracle's result."""
+    import XbitOps
+    from xbitops_amd import _lib
+
+    lib = _lib.load()
+    k, n = 16384, 512
+    p = synth.make_problem(k, n, 4, 128, m=1, seed=98)
+    y_ref = oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, 4, k, 1, oracle.RNE)
+    a, qw, sc, qz = to_dev(p, cuda_device)
+    assert lib.xbit_workspace_reset() == 0  # creates the pool
+    assert lib.xbit_workspace_release() == 0
+    whole = lib.xbit_workspace_capture_bytes_free()
+    assert whole == 8 << 20
+    stream = torch.cuda.Stream(device=cuda_device)
+    graphs = []
+    with torch.cuda.stream(stream):
+        XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        stream.synchronize()
+        for _ in range(2):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                y = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+            graphs.append((graph, y))
+        after_two = lib.xbit_workspace_capture_bytes_free()
+        assert whole - after_two == 2 * 8 * n  # 8 bytes per output element and captured launch
+        for graph, y in graphs:
+            graph.replay()
+        stream.synchronize()
+        for _graph, y in graphs:
+            assert_gemv_close(y.cpu().numpy(), y_ref, "captured split-K")
+        del graphs, graph
+        assert lib.xbit_workspace_release() == 0
+        assert lib.xbit_workspace_capture_bytes_free() == whole
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            y = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+        assert lib.xbit_workspace_capture_bytes_free() == whole - 8 * n
+        y.zero_()
+        graph.replay()
+        stream.synchronize()
+    assert_gemv_close(y.cpu().numpy(), y_ref, "captured after release")
+
+
 @pytest.mark.parametrize("bits", [3, 4, 8])
 def test_gemv_multi_fused_launch(bits, cuda_device):
     """xbit_gemv_multi_f16: q/k/v-style (equal N), gate/up-style, ragged and single sets in one launch at

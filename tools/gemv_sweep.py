@@ -88,8 +88,6 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, spli
     base = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
     act = torch.from_numpy(base.act).to(dev)
     qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
-    if 210 <= variant <= 239:  # tile-contiguous address probes read a stream up to 1/8 longer than qweight (meta rows): give them real memory
-        qw = [torch.cat([t, t[: t.shape[0] // 8]]).contiguous() for t in qw]
     sc = [torch.from_numpy(base.scales).to(dev).clone() for c in range(copies)]
     qz = [torch.from_numpy(base.qzeros).to(dev).clone() for c in range(copies)]
     out = torch.empty((m, n), dtype=torch.float16, device=dev)
@@ -99,15 +97,7 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, spli
 
     def fn(i):
         c = i % copies
-        o = opts
-        if variant == 254:  # prefetch copy c with a separate launch of the prefetch workgroups alone, then time the production-shape kernel on it
-            pre = _lib.GemvOptions(variant=251, workspace=qw[c].data_ptr(), workspace_bytes=qw[0].numel() * 4)
-            st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[(c + 3) % copies].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, pre)
-            assert st == 0, st
-            o = _lib.GemvOptions(variant=15)
-        if 250 <= variant <= 253 or 255 <= variant <= 258:  # prototype: this call also prefetches the NEXT call's packed weights (passed in options.workspace)
-            o = _lib.GemvOptions(variant=variant, workspace=qw[(c + 1) % copies].data_ptr(), workspace_bytes=qw[0].numel() * 4)
-        st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, o)
+        st = lib.xbit_gemv_f16_ex(out.data_ptr(), act.data_ptr(), qw[c].data_ptr(), sc[c].data_ptr(), qz[c].data_ptr(), bits, g, m, k, n, 1, sp, opts)
         assert st == 0, st
 
     avg, med, mn = measure(lib, fn, iters, warm_launches)

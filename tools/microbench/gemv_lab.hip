@@ -134,6 +134,9 @@ static Candidate dyn_candidate(const char* name, const Problem& pr, Device& d) {
   p.gshift = 0;
   while ((32u * UB << p.gshift) < pr.g) ++p.gshift;
   p.act_bytes = p.units * LK * UB * 64u;
+  p.m = 1;
+  p.splits = 1;
+  p.ups = p.units;
   p.tab_groups = ((p.units * LK - 1u) >> p.gshift) + 1u;
   if (p.tab_groups < p.groups) p.tab_groups = p.groups;
   constexpr uint32_t st = 64u * STW;  // staging threads
@@ -142,7 +145,7 @@ static Candidate dyn_candidate(const char* name, const Problem& pr, Device& d) {
     fprintf(stderr, "%s: SI too small for this shape\n", name);
     exit(1);
   }
-  const size_t lds = xbit::dyn::dyn_lds_bytes(p, NL, NW, CPL);
+  const size_t lds = xbit::dyn::dyn_lds_bytes(p, NL, NW, CPL, 1);
   auto kern = xbit::dyn::gemv_dyn_kernel<4, UB, CPL, NL, NW, NT, SI, STW, LA, FLAGS>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   cd.launch = [=, &d](int c, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
@@ -154,7 +157,7 @@ static Candidate dyn_candidate(const char* name, const Problem& pr, Device& d) {
     q.out = d.out;
     q.trace = d.trace;
     hipExtLaunchKernelGGL(kern, dim3(q.tiles), dim3(64 * NW), lds, s, start, stop, 0, q.qweight, q.n, q.tiles, q.kw, q.units, q.a, q.scales, q.qzeros, q.out,
-                          q.k, q.groups, q.zw, q.bias, q.tab_groups, q.gshift, q.act_bytes, q.trace);
+                          q.k, q.groups, q.zw, q.bias, q.m, q.tab_groups, q.gshift, q.act_bytes, q.splits, q.ups, q.acc, q.g_idx, q.trace);
   };
   return cd;
 }

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--variants", default="399,300,301,302,303,304,-1")
     ap.add_argument("--group", type=int, default=128)
+    ap.add_argument("--rows", default="1", help="activation rows per launch (the staged-operand kernel takes 1..4)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load_tuning()
@@ -36,15 +37,15 @@ def main():
         " ".join(str(v) for v in variants)), flush=True)
     for shape in args.shapes.split(","):
         k, n = (int(x) for x in shape.split("x"))
-        for bits in (int(b) for b in args.bits.split(",")):
+        for bits, m in ((int(b), int(r)) for b in args.bits.split(",") for r in args.rows.split(",")):
             cells = []
             for v in variants:
                 try:
-                    nbytes, _avg, med, _mn = gemv_sweep.gemv_case(lib, dev, k, n, bits, args.group, 1, True, 80 if k * n > 5e7 else 120, v, 0)
+                    nbytes, _avg, med, _mn = gemv_sweep.gemv_case(lib, dev, k, n, bits, args.group, m, True, 80 if k * n > 5e7 else 120, v, 0)
                     cells.append("%7.2f" % med)
                 except AssertionError:
                     cells.append("    n/a")
-            print("w%d %-12s %6.1f MB  %s" % (bits, shape, synth.algorithmic_bytes(k, n, bits, args.group, 1) / 1e6, " ".join(cells)), flush=True)
+            print("w%d %-12s m%d %6.1f MB  %s" % (bits, shape, m, synth.algorithmic_bytes(k, n, bits, args.group, m) / 1e6, " ".join(cells)), flush=True)
 
 
 if __name__ == "__main__":

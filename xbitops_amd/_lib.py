@@ -25,6 +25,8 @@ EXPORTS = (
     "xbit_gemv_f16_ex",
     "xbit_gemv_workspace_bytes",
     "xbit_workspace_reset",
+    "xbit_workspace_release",
+    "xbit_workspace_capture_bytes_free",
     "xbit_gemv_gidx_f16",
     "xbit_dequant_gidx_f16",
     "xbit_gemv_multi_f16",
@@ -81,6 +83,10 @@ def _typed(path: str) -> ctypes.CDLL:
     lib.xbit_gemv_workspace_bytes.argtypes = [u32, u32]
     lib.xbit_workspace_reset.restype = ci
     lib.xbit_workspace_reset.argtypes = []
+    lib.xbit_workspace_release.restype = ci
+    lib.xbit_workspace_release.argtypes = []
+    lib.xbit_workspace_capture_bytes_free.restype = ctypes.c_uint64
+    lib.xbit_workspace_capture_bytes_free.argtypes = []
     lib.xbit_gemv_gidx_f16.restype = ci
     lib.xbit_gemv_gidx_f16.argtypes = [vp, vp, vp, vp, vp, vp, ci, u32, u32, u32, u32, u8, vp]
     lib.xbit_dequant_gidx_f16.restype = ci

@@ -77,7 +77,7 @@ int launch_raw_dynamic(const void* kernel, dim3 grid, dim3 block, size_t dynamic
 // ---- split-K scratch -------------------------------------------------------------------------------
 namespace {
 constexpr size_t kStreamSlots = kMaxSplitSlots;       // per (device, stream) buffer for eager launches: 2 MiB
-constexpr size_t kPoolSlots = (size_t)1 << 20;        // per-device pool for captured launches: 8 MiB, never recycled
+constexpr size_t kPoolSlots = (size_t)1 << 20;        // per-device pool for captured launches: 8 MiB; ranges go back only through xbit_workspace_release
 struct CapturePool {
   unsigned long long* base = nullptr;
   size_t used = 0;
@@ -85,7 +85,8 @@ struct CapturePool {
 std::mutex g_ws_mutex;
 std::map<std::pair<int, hipStream_t>, GemvWorkspace> g_ws;  // lives as long as the process
 std::map<int, CapturePool> g_pool;
-std::atomic<bool> g_ws_dirty{false};
+std::atomic<uint64_t> g_ws_dirty{0};  // bit d: a launch failed on device d, its accumulators may hold partial sums (devices >= 64 share bit 63)
+inline uint64_t dirty_bit(int dev) { return 1ull << (dev < 0 ? 0 : (dev > 63 ? 63 : dev)); }
 
 // hipMalloc + zero-fill; never called for a capturing stream (allocation inside a capture is not legal)
 unsigned long long* alloc_zeroed(size_t slots) {
@@ -115,7 +116,15 @@ int reset_workspaces_locked(int dev) {
 }
 }  // namespace
 
-void mark_workspaces_dirty() { g_ws_dirty.store(true, std::memory_order_relaxed); }
+void mark_workspaces_dirty() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    g_ws_dirty.store(~0ull, std::memory_order_relaxed);  // which device is unknown: every one re-zeroes before its next split launch
+    return;
+  }
+  g_ws_dirty.fetch_or(dirty_bit(dev), std::memory_order_relaxed);
+}
 
 bool gemv_workspace(hipStream_t stream, size_t slots, const GemvLaunchOpts& opts, GemvWorkspace* out) {
   if (slots == 0 || slots > kMaxSplitSlots) return false;
@@ -148,14 +157,16 @@ bool gemv_workspace(hipStream_t stream, size_t slots, const GemvLaunchOpts& opts
     pool.used += (slots + 15) & ~(size_t)15;  // 128-byte granules: ranges never share a cache line
     return true;
   }
-  if (g_ws_dirty.exchange(false, std::memory_order_relaxed)) {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;  // another thread may be capturing in global mode: the sync, memset and malloc below must not break its capture
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (g_ws_dirty.load(std::memory_order_relaxed) & dirty_bit(dev)) {  // this device only: another device's flag stays up until a launch there
+    g_ws_dirty.fetch_and(~dirty_bit(dev), std::memory_order_relaxed);
     if (reset_workspaces_locked(dev) != XBIT_OK) {
-      g_ws_dirty.store(true, std::memory_order_relaxed);
+      g_ws_dirty.fetch_or(dirty_bit(dev), std::memory_order_relaxed);
+      (void)hipThreadExchangeStreamCaptureMode(&mode);
       return false;
     }
   }
-  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;  // another thread may be capturing in global mode
-  (void)hipThreadExchangeStreamCaptureMode(&mode);
   CapturePool& pool = g_pool[dev];
   if (!pool.base) pool.base = alloc_zeroed(kPoolSlots);  // a failure is not remembered: the next launch tries again
   GemvWorkspace& ws = g_ws[{dev, stream}];
@@ -295,7 +306,38 @@ int xbit_workspace_reset(void) {
   std::lock_guard<std::mutex> lock(xbit::g_ws_mutex);
   xbit::CapturePool& pool = xbit::g_pool[dev];
   if (!pool.base) pool.base = xbit::alloc_zeroed(xbit::kPoolSlots);  // so that a capture may come before any eager launch
-  return xbit::reset_workspaces_locked(dev);
+  xbit::g_ws_dirty.fetch_and(~xbit::dirty_bit(dev), std::memory_order_relaxed);
+  const int st = xbit::reset_workspaces_locked(dev);
+  if (st != XBIT_OK) xbit::g_ws_dirty.fetch_or(xbit::dirty_bit(dev), std::memory_order_relaxed);
+  return st;
+}
+
+int xbit_workspace_release(void) {
+  int dev = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)err;
+  }
+  std::lock_guard<std::mutex> lock(xbit::g_ws_mutex);
+  auto it = xbit::g_pool.find(dev);
+  if (it == xbit::g_pool.end() || !it->second.base) return XBIT_OK;
+  // waits for everything in flight on the device, re-zeroes, then hands the whole pool out again
+  const int st = xbit::reset_workspaces_locked(dev);
+  if (st == XBIT_OK) it->second.used = 0;
+  return st;
+}
+
+uint64_t xbit_workspace_capture_bytes_free(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(xbit::g_ws_mutex);
+  auto it = xbit::g_pool.find(dev);
+  if (it == xbit::g_pool.end() || !it->second.base) return 0;
+  return (uint64_t)(xbit::kPoolSlots - it->second.used) * sizeof(unsigned long long);
 }
 
 static int gidx_params(xbit::GemvGidxParams* p, void* out, const void* a, const void* qweight, const void* scales, const void* qzeros,

@@ -236,14 +236,17 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1,
 
 // Fully general fallback: any n, any group size (16, 48, ... - a group may begin anywhere inside a k-block), any k, M rows,
 // tensors aligned to their element size only.  A workgroup owns 64 adjacent columns (one per lane: every packed row is
-// one coalesced 256-byte read per wave) over all of K; its four waves take every fourth k-block; a lane unpacks its
+// one coalesced 256-byte read per wave) over all of K; its sixteen waves take every sixteenth k-block (the next one's rows
+// are requested before this one's are unpacked); a lane unpacks its
 // column's 32 fields with compile-time shifts, looks the (scale, zero-point) pair up again whenever the group changes
 // (wave-uniform), rebuilds W exactly as the fast kernels do and accumulates in fp32; the activations of a k-block sit one
 // per lane and are broadcast with v_readlane.  Replaces the round-1 kernel that gave every OUTPUT ELEMENT a workgroup
 // and gathered each field with its own 4-byte read (profiles/r03/sweep_ragged_shapes.txt).
+constexpr int kColumnWaves = 16;
 template <int BITS, int MT>
-__global__ void __launch_bounds__(256) gemv_columns_kernel(const GemvParams p) {
-  __shared__ float s_part[4][MT][64];
+__global__ void __launch_bounds__(64 * kColumnWaves) gemv_columns_kernel(const GemvParams p) {
+  constexpr uint32_t NW = kColumnWaves;
+  __shared__ float s_part[NW][MT][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t col = blockIdx.x * 64u + (uint32_t)lane, m0 = blockIdx.y * (uint32_t)MT;
@@ -252,13 +255,19 @@ __global__ void __launch_bounds__(256) gemv_columns_kernel(const GemvParams p) {
   float acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-  for (uint32_t kb = (uint32_t)wv; kb < kblocks; kb += 4u) {
-    uint32_t w[BITS];
+  auto rows_of = [&](uint32_t kb, uint32_t(&w)[BITS]) {
 #pragma unroll
     for (int i = 0; i < BITS; ++i) {
       const uint32_t row = kb * (uint32_t)BITS + (uint32_t)i;
       w[i] = (col_ok && row < p.kw) ? p.qweight[(size_t)row * p.n + col] : 0u;
     }
+  };
+  uint32_t w[BITS], w_next[BITS];
+  rows_of((uint32_t)wv, w_next);
+  for (uint32_t kb = (uint32_t)wv; kb < kblocks; kb += NW) {
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) w[i] = w_next[i];
+    rows_of(kb + NW, w_next);  // past the last k-block: zeros, no traffic
     // activation k = 32 * kb + (lane & 31) of each row, as fp32 bits (both halves of the wave hold the same 32 values)
     uint32_t av[MT];
     const uint32_t k_l = kb * 32u + (uint32_t)(lane & 31);
@@ -294,15 +303,17 @@ __global__ void __launch_bounds__(256) gemv_columns_kernel(const GemvParams p) {
   __syncthreads();
   if (tid < 64 * MT) {
     const int m = tid >> 6;
-    const float sum = s_part[0][m][lane] + s_part[1][m][lane] + s_part[2][m][lane] + s_part[3][m][lane];
+    float sum = 0.f;
+#pragma unroll
+    for (uint32_t v = 0; v < NW; ++v) sum += s_part[v][m][lane];
     if (col_ok && m0 + (uint32_t)m < p.m) p.out[(size_t)(m0 + (uint32_t)m) * p.n + col] = as_u16((_Float16)sum);
   }
 }
 
 template <int BITS>
 int launch_columns(const GemvParams& p, hipStream_t stream) {
-  if (p.m == 1u) return launch(gemv_columns_kernel<BITS, 1>, dim3((p.n + 63u) / 64u, 1), dim3(256), stream, p);
-  return launch(gemv_columns_kernel<BITS, 4>, dim3((p.n + 63u) / 64u, (p.m + 3u) / 4u), dim3(256), stream, p);
+  if (p.m == 1u) return launch(gemv_columns_kernel<BITS, 1>, dim3((p.n + 63u) / 64u, 1), dim3(64 * kColumnWaves), stream, p);
+  return launch(gemv_columns_kernel<BITS, 4>, dim3((p.n + 63u) / 64u, (p.m + 3u) / 4u), dim3(64 * kColumnWaves), stream, p);
 }
 
 #if XBIT_TUNING
@@ -374,9 +385,11 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
 #endif
   if (mfma_ok) return launch_gemv_mfma(p, bits, stream, opts);
   // One row of any length k (the reference harness's own K = 7167, main.cc:21): the staged-operand kernel masks the tail
-  // of the activation vector itself, so only group sizes that are not a multiple of 32 (or tensors that are not even
-  // 4-byte aligned, or 2 GiB and more) go on to the column kernel below.
-  if (p.m == 1u && small && p.groupsize % 32u == 0 && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
+  // of the activation vector itself.  Group sizes that are not a multiple of 32 (16, 48, 80 ...; one to four rows): the
+  // same kernel's by-id build, which looks every row's group up (ids computed as k / groupsize).  What is left for the
+  // column kernel below: ragged k with several rows, more than four rows of an odd group size, tensors that are not
+  // 4-byte aligned or reach 2 GiB (profiles/r03/sweep_ragged_shapes.txt).
+  if (p.m <= 4u && (p.m == 1u || p.k % 8u == 0u) && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
     const int st = launch_gemv_dyn(p, bits, stream, pick_cpl(p.n), 16, true, false, nullptr);
     if (st != kGemvDynNotEligible) return st;
   }

@@ -1,4 +1,4 @@
-// xbit_gemv_dyn.h — A16Wx GEMV for ONE activation row (decode), gfx950, bits 2..8: whole-K column tiles, small
+// xbit_gemv_dyn.h — A16Wx GEMV for one to four activation rows (decode), gfx950, bits 2..8: whole-K column tiles, small
 // operands staged once per workgroup by HALF of its waves while the other half already streams weights.
 //
 // Same packed layout, same arithmetic and the same lane map as xbit_gemv_mfma.h (NL lanes x CPL adjacent columns,
@@ -90,18 +90,22 @@ struct Plan {
 struct DynParams {
   const uint32_t* qweight;  // [kw, n]
   uint32_t n, tiles, kw, units;  // units = ceil(k-blocks / (LK * UB)): wave w works on units w, w + NW, ...
-  const uint16_t* a;        // fp16 [k]
+  const uint16_t* a;        // fp16 [m, k]
   const uint16_t* scales;   // fp16 [groups, n]
   const uint32_t* qzeros;   // [groups, zw]
-  uint16_t* out;            // fp16 [n]
+  uint16_t* out;            // fp16 [m, n]
   uint32_t k, groups, zw, bias;
+  uint32_t m;               // rows (<= MT)
   uint32_t tab_groups;      // rows of the LDS table: every group a k-slot of [0, LK * units) can name (>= groups; the extra rows are zeros)
   uint32_t gshift;          // log2(groupsize / (32 * UB)): k-slot batch t = unit * LK + kl belongs to group t >> gshift
   uint32_t act_bytes;       // LDS bytes of the staged activation vector: (units of one K range) * LK * UB * 64
   uint32_t splits, ups;     // split-K builds: K ranges per tile and units per range (whole-K: 1, units)
   unsigned long long* acc;  // split-K builds: one 64-bit accumulator per output element, zero between launches
-  const int32_t* g_idx;     // act-order builds: the group of row k (k entries; values are clamped to [0, groups))
+  const int32_t* g_idx;     // act-order builds: the group of row k (k entries; values are clamped to [0, groups)); null there = the
+                            // ids are computed, row k belongs to group k / gshift (gshift holds the GROUP SIZE in those launches):
+                            // group sizes that are no multiple of 32 (16, 48, 80 ...), where a group may begin inside a k-block
   uint64_t* trace;          // stamped build only
+  bool by_id;               // host side only: launch the act-order build
 };
 
 // Template parameters
@@ -121,14 +125,16 @@ struct DynParams {
 //          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
 //          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
 //          column more than the contiguous build, no change to the weight stream.
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false, bool GIDX = false>
+//   MT     activation rows per launch (1 or 4): the MFMA's A operand carries row (lane & 15) % MT, the staged activation
+//          image holds MT rows per octet, D rows 0..MT-1 are the results (the rest are copies)
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1>
 __global__ void __launch_bounds__(64 * NW)
     gemv_dyn_kernel(const uint32_t* qweight, uint32_t n, uint32_t tiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales,
-                    const uint32_t* qzeros, uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t tab_groups, uint32_t gshift,
+                    const uint32_t* qzeros, uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t m, uint32_t tab_groups, uint32_t gshift,
                     uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, const int32_t* g_idx, uint64_t* trace) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace};
+  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
@@ -142,15 +148,16 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(NL == 16 || NL == 8, "lanes along N");
   static_assert(STW >= 1 && STW <= NW, "staging waves");
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
+  static_assert(MT == 1 || MT == 4, "rows per launch");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
-  //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * CN floats][bad flags: 8 dwords]
+  //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * MT * CN floats][bad flags: 8 dwords]
   uint32_t* const s_act = s_dyn;
   uint32_t* const s_gid = s_act + p.act_bytes / 4u;
-  uint32_t* const s_tab = s_gid + (GIDX ? p.act_bytes / 4u : 0u);
+  uint32_t* const s_tab = s_gid + (GIDX ? p.act_bytes / (4u * MT) : 0u);  // ids: 2 B per k, whatever MT
   uint32_t* const s_tab_plain = s_tab + (GIDX ? p.tab_groups * (uint32_t)(NL * 4) : 0u);
   float* const s_red = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
-  uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * CN + 3) & ~3));
+  uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * MT * CN + 3) & ~3));
 
   const int tid = threadIdx.x, lane = tid & 63, kl = lane / NL, nl = lane % NL;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: unit numbers ride in scalar offsets
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(64 * NW)
   const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
   const bool col_ok = col < p.n;
   const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
-  const rsrc_t r_a = make_rsrc(p.a, (p.k * 2u + 3u) & ~3u);  // odd k: the last element's dword must be in range (its other half is masked below)
+  const rsrc_t r_a = make_rsrc(p.a, (p.m * p.k * 2u + 3u) & ~3u);  // odd k: the last element's dword must be in range (its other half is masked below)
   const rsrc_t r_s = make_rsrc(p.scales, p.groups * p.n * 2u);
   const rsrc_t r_z = make_rsrc(p.qzeros, p.groups * p.zw * 4u);
   const bool stager = wv < STW;  // wave-uniform
@@ -175,50 +182,70 @@ __global__ void __launch_bounds__(64 * NW)
   // (a) activations: chunk c = k CHK*c .. CHK*c + CHK - 1; (b) per group and column: scale and zero-point of staging
   // thread e's (group e / NL, lane slot e % NL).  Rounds past the end fall off the end of their tensors (the descriptors
   // return zeros, no traffic); lane slots past the last column read some other column's values, which are never stored.
-  u32x4_t act_raw[SI][CPT];
+  u32x4_t act_raw[SI][MT][CPT];
   uint32_t s_raw[SI][2], z_raw[SI][2];
   u32x4_t g_raw[GIDX ? SI : 1][2];  // act-order: the ids of 8 consecutive rows per round
   const rsrc_t r_g = make_rsrc(GIDX ? static_cast<const void*>(p.g_idx) : static_cast<const void*>(p.a), GIDX ? p.k * 4u : 0u);
+  // table entry e = (group gbase + e / NL, lane slot e % NL): its scale word(s) and zero-point word(s)
+  auto tab_load = [&](uint32_t e, uint32_t(&sr)[2], uint32_t(&zr)[2]) {
+    const uint32_t g = gbase + e / NL, snl = e % NL;
+    const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
+    const uint32_t h0 = g * p.n + scol;  // first scale (half index)
+    if constexpr (CPL == 2) {
+      sr[0] = __builtin_amdgcn_raw_buffer_load_b32(r_s, h0 * 2u, 0, 0);  // n and col even
+      sr[1] = 0;
+    } else {
+      const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_s, (h0 & ~1u) * 2u, 0, 0);
+      sr[0] = v.x;
+      sr[1] = v.y;
+    }
+    const uint32_t bit = scol * BITS;
+    const uint32_t zoff = (g * p.zw + (bit >> 5)) * 4u;
+    if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
+      zr[0] = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0);  // the CPL fields never straddle a word
+      zr[1] = 0;
+    } else {
+      const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_z, zoff, 0, 0);  // a read past the row end is harmless
+      zr[0] = v.x;
+      zr[1] = v.y;
+    }
+  };
   if (stager) {
     if constexpr (GIDX) {
+      if (p.g_idx != nullptr) {  // uniform
 #pragma unroll
-      for (int r = 0; r < SI; ++r) {
-        const uint32_t c = (uint32_t)(r * ST + tid);
-        g_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u, 0, 0);  // rows past k read id 0: their activations are 0
-        g_raw[r][1] = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u + 16u, 0, 0);
+        for (int r = 0; r < SI; ++r) {
+          const uint32_t c = (uint32_t)(r * ST + tid);
+          g_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u, 0, 0);  // rows past k read id 0: their activations are 0
+          g_raw[r][1] = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u + 16u, 0, 0);
+        }
+      } else {  // contiguous groups of ANY size: id = row / group size, one division per 8 rows
+#pragma unroll
+        for (int r = 0; r < SI; ++r) {
+          const uint32_t k0 = (uint32_t)(r * ST + tid) * 8u;
+          uint32_t q = k0 / p.gshift, rem = k0 - q * p.gshift;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            g_raw[r][j >> 2][j & 3] = q;
+            if (++rem == p.gshift) rem = 0u, ++q;
+          }
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < SI; ++r) {
       const uint32_t c = (uint32_t)(r * ST + tid);
 #pragma unroll
-      for (int q = 0; q < CPT; ++q)  // dwords past the end of the vector read 0; a last dword that holds ONE element is masked when staged
-        act_raw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, (SPLIT && c * (uint32_t)(CHK * 2) >= p.act_bytes) ? kOob : (cbase + c) * (uint32_t)(CHK * 2) + 16u * q, 0, 0);
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {  // dwords past the end of the tensor read 0; a last dword that holds ONE element is masked when staged
+          // rows beyond m fall off the end of the tensor; chunks beyond this range's k must not read on into the next row (MT > 1) or range (split)
+          const bool out_of_range = ((SPLIT || MT > 1) && c * (uint32_t)(CHK * 2 * MT) >= p.act_bytes) || (MT > 1 && (cbase + c) * (uint32_t)CHK + 8u * q >= p.k);
+          act_raw[r][mi][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, out_of_range ? kOob : ((uint32_t)mi * p.k + (cbase + c) * (uint32_t)CHK) * 2u + 16u * q, 0, 0);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < SI; ++r) {
-      const uint32_t e = (uint32_t)(r * ST + tid), g = gbase + e / NL, snl = e % NL;
-      const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
-      const uint32_t h0 = g * p.n + scol;  // first scale (half index)
-      if constexpr (CPL == 2) {
-        s_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b32(r_s, h0 * 2u, 0, 0);  // n and col even
-        s_raw[r][1] = 0;
-      } else {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_s, (h0 & ~1u) * 2u, 0, 0);
-        s_raw[r][0] = v.x;
-        s_raw[r][1] = v.y;
-      }
-      const uint32_t bit = scol * BITS;
-      const uint32_t zoff = (g * p.zw + (bit >> 5)) * 4u;
-      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
-        z_raw[r][0] = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0);  // the CPL fields never straddle a word
-        z_raw[r][1] = 0;
-      } else {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_z, zoff, 0, 0);  // a read past the row end is harmless
-        z_raw[r][0] = v.x;
-        z_raw[r][1] = v.y;
-      }
-    }
+    for (int r = 0; r < SI; ++r) tab_load((uint32_t)(r * ST + tid), s_raw[r], z_raw[r]);
   }
 
   // ---- the first weight rows of this wave ----
@@ -250,48 +277,51 @@ __global__ void __launch_bounds__(64 * NW)
 #pragma unroll
     for (int r = 0; r < SI; ++r) {
       const uint32_t c = (uint32_t)(r * ST + tid);
-      uint32_t h[CHK / 2];
 #pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        h[4 * q + 0] = act_raw[r][q].x;
-        h[4 * q + 1] = act_raw[r][q].y;
-        h[4 * q + 2] = act_raw[r][q].z;
-        h[4 * q + 3] = act_raw[r][q].w;
-      }
-      {
-        // k is any length: elements at k and beyond count as 0 (the packed rows hold padding fields there).  Only an odd
-        // k leaves something to clear - the upper half of the dword that holds element k - 1.
-        const int left = (int)p.k - (int)((cbase + c) * (uint32_t)CHK);  // elements of this chunk inside the vector
+      for (int mi = 0; mi < MT; ++mi) {
+        uint32_t h[CHK / 2];
 #pragma unroll
-        for (int d = 0; d < CHK / 2; ++d) h[d] = left >= 2 * d + 2 ? h[d] : (left == 2 * d + 1 ? (h[d] & 0xFFFFu) : 0u);
-      }
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        u32x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // pair (4q + e) of this chunk in the unpacker's order; pair_k is periodic in the chunk
-          const int pr = 4 * q + e;
-          const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
-          static_assert(Unpack<BITS>::pair_k(CHK / 2 - 1, 1) < CHK, "pairs stay inside a chunk");
-          const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) | ((uint32_t)(4 + 2 * (khi & 1)) << 16) |
-                               ((uint32_t)(5 + 2 * (khi & 1)) << 24);
-          o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+        for (int q = 0; q < CPT; ++q) {
+          h[4 * q + 0] = act_raw[r][mi][q].x;
+          h[4 * q + 1] = act_raw[r][mi][q].y;
+          h[4 * q + 2] = act_raw[r][mi][q].z;
+          h[4 * q + 3] = act_raw[r][mi][q].w;
         }
-        if (c * (uint32_t)(CHK * 2) < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_act + c * (uint32_t)(CHK / 2) + 4 * q) = o;
+        {
+          // k is any length (one row): elements at k and beyond count as 0 (the packed rows hold padding fields there).
+          // Only an odd k leaves something to clear - the upper half of the dword that holds element k - 1.
+          const int left = (int)p.k - (int)((cbase + c) * (uint32_t)CHK);  // elements of this chunk inside the row
+#pragma unroll
+          for (int d = 0; d < CHK / 2; ++d) h[d] = left >= 2 * d + 2 ? h[d] : (left == 2 * d + 1 ? (h[d] & 0xFFFFu) : 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // pair (4q + e) of this chunk in the unpacker's order; pair_k is periodic in the chunk
+            const int pr = 4 * q + e;
+            const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
+            static_assert(Unpack<BITS>::pair_k(CHK / 2 - 1, 1) < CHK, "pairs stay inside a chunk");
+            const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) | ((uint32_t)(4 + 2 * (khi & 1)) << 16) |
+                                 ((uint32_t)(5 + 2 * (khi & 1)) << 24);
+            o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+          }
+          // octet (c * CPT + q) of the range, row mi: 16 bytes at ((octet * MT) + mi) * 16
+          if (c * (uint32_t)(CHK * 2 * MT) < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_act + ((c * (uint32_t)CPT + (uint32_t)q) * (uint32_t)MT + (uint32_t)mi) * 4u) = o;
+        }
       }
     }
-#pragma unroll
-    for (int r = 0; r < SI; ++r) {
-      const uint32_t e = (uint32_t)(r * ST + tid), g = gbase + e / NL, snl = e % NL;
+    auto tab_store = [&](uint32_t e, const uint32_t(&sr)[2], const uint32_t(&zr)[2]) {
+      const uint32_t g = gbase + e / NL, snl = e % NL;
       const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
       uint32_t sb[CPL];
       if constexpr (CPL == 2) {
-        sb[0] = s_raw[r][0] & 0xFFFFu;
-        sb[1] = s_raw[r][0] >> 16;
+        sb[0] = sr[0] & 0xFFFFu;
+        sb[1] = sr[0] >> 16;
       } else {
         const uint32_t sh = ((g * p.n + scol) & 1u) * 16u;
-        const uint32_t lo = __builtin_amdgcn_alignbit(s_raw[r][1], s_raw[r][0], sh), hi = s_raw[r][1] >> sh;
+        const uint32_t lo = __builtin_amdgcn_alignbit(sr[1], sr[0], sh), hi = sr[1] >> sh;
         sb[0] = lo & 0xFFFFu;
         sb[1] = lo >> 16;
         sb[2] = hi & 0xFFFFu;
@@ -299,8 +329,8 @@ __global__ void __launch_bounds__(64 * NW)
       }
       const uint32_t zsh = (scol * BITS) & 31u;
       uint32_t zwin;
-      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) zwin = z_raw[r][0] >> zsh;
-      else zwin = __builtin_amdgcn_alignbit(z_raw[r][1], z_raw[r][0], zsh);
+      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) zwin = zr[0] >> zsh;
+      else zwin = __builtin_amdgcn_alignbit(zr[1], zr[0], zsh);
       u32x4_t ent = {0u, 0u, 0u, 0u};  // (scale | -(zero + bias) * scale << 16) per column
       u32x4_t ent_sub = {0u, 0u, 0u, 0u};  // act-order: the scale pre-multiplied for the subnormal form (a pair mixes two groups)
 #pragma unroll
@@ -322,6 +352,17 @@ __global__ void __launch_bounds__(64 * NW)
           *reinterpret_cast<u32x4_t*>(s_tab + e * 4u) = ent;
         }
       }
+    };
+#pragma unroll
+    for (int r = 0; r < SI; ++r) tab_store((uint32_t)(r * ST + tid), s_raw[r], z_raw[r]);
+    if constexpr (GIDX) {
+      // more groups than SI rounds of table entries (small or odd group sizes: K = 4096 at group 16 has 256): the rest one
+      // round at a time, load -> store.  Only the by-id build pays for the loop; its table holds every group of the layer.
+      for (uint32_t e = (uint32_t)(SI * ST + tid); e < p.tab_groups * (uint32_t)NL; e += (uint32_t)ST) {
+        uint32_t sr[2], zr[2];
+        tab_load(e, sr, zr);
+        tab_store(e, sr, zr);
+      }
     }
     if constexpr (GIDX) {
 #pragma unroll
@@ -334,7 +375,7 @@ __global__ void __launch_bounds__(64 * NW)
           const uint32_t lo = d < 2 ? g_raw[r][0][2 * d] : g_raw[r][1][2 * d - 4], hi = d < 2 ? g_raw[r][0][2 * d + 1] : g_raw[r][1][2 * d - 3];
           o[d] = (lo < top ? lo : top) | ((hi < top ? hi : top) << 16);  // out-of-range (or negative) ids are clamped, never followed
         }
-        if (c * 16u < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_gid + c * 4u) = o;
+        if (c * (16u * MT) < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_gid + c * 4u) = o;
       }
     }
   }
@@ -353,7 +394,8 @@ __global__ void __launch_bounds__(64 * NW)
   for (int c = 0; c < CPL; ++c) acc[c] = f4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
-  const uint32_t a_lane = (uint32_t)(kl * UB) * 16u;  // dwords: this lane's k-blocks of the unit, 4 octets x 4 dwords each
+  // dwords: this lane's k-blocks of the unit (4 octets each, MT rows of 4 dwords per octet), its row of the A operand
+  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(16 * MT) + (uint32_t)(nl % MT) * 4u;
 
   // per-unit dequant constants of this lane's columns
   auto unit_consts = [&](uint32_t u, half2_t(&s2)[CPL], half2_t(&nzs2)[CPL], half2_t(&ss2)[CPL]) {
@@ -374,7 +416,7 @@ __global__ void __launch_bounds__(64 * NW)
                   const half2_t(&ss2)[CPL], const uint32_t(&gq)[GIDX ? UB : 1][16]) {
     constexpr int s = decltype(s_c)::value, j = s / 4, oct = s % 4;
     constexpr bool FAST = decltype(fast_c)::value;
-    const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + j * 16 + 4 * oct);
+    const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 16 + 4 * oct) * MT);
     const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
     uint32_t wc[CPL][BITS];
 #pragma unroll
@@ -437,7 +479,7 @@ __global__ void __launch_bounds__(64 * NW)
   auto process = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R]) {
     const bool live = cur < uend;  // wave-uniform
     half2_t s2[CPL], nzs2[CPL], ss2[CPL];
-    const uint32_t* const a_unit = s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16) + a_lane;
+    const uint32_t* const a_unit = s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
     uint32_t gq[GIDX ? UB : 1][16];
     if (live) {
       if constexpr (GIDX) unit_ids(cur, gq);
@@ -475,7 +517,7 @@ __global__ void __launch_bounds__(64 * NW)
       Row<CPL, NT> rs[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) rs[i].load(r_w, lane_off, u * unit_bytes + (uint32_t)i * row_bytes);
-      const uint32_t* const a_unit = s_act + (u - ubeg) * (uint32_t)(LK * UB * 16) + a_lane;
+      const uint32_t* const a_unit = s_act + (u - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
       static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2, gq); });
     }
   }
@@ -485,31 +527,35 @@ __global__ void __launch_bounds__(64 * NW)
   }
 
   // ---- cross-wave sum.  D[row][slot]: row 4 * (lane >> 4) + r lives in register r of lane (lane >> 4, slot = lane & 15).
-  // NL = 16: row 0 (register 0 of lanes 0-15) is the sum over the wave's four k-slots for column slot = nl.
-  // NL = 8: even k-slots sum into D[0][0..7] (lanes 0-7), odd ones into D[8][8..15] (lanes 40-47). ----
+  // NL = 16: rows 0..MT-1 (registers 0..MT-1 of lanes 0-15) are the sums over the wave's four k-slots for column slot = nl.
+  // NL = 8: even k-slots sum into D[m][0..7] (lanes 0-7), odd ones into D[8 + m][8..15] (lanes 40-47). ----
   {
     const int h = NL == 16 ? 0 : (lane >= 32 ? 1 : 0);
     const bool holder = NL == 16 ? lane < 16 : (lane < 8 || (lane >= 40 && lane < 48));
     if (holder) {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) s_red[(wv * HS + h) * CN + (lane % NL) * CPL + c] = acc[c][0];
+      for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) s_red[((wv * HS + h) * MT + mi) * CN + (lane % NL) * CPL + c] = acc[c][mi];
     }
   }
   __syncthreads();
   if constexpr (STAMP) stamp[4] = __builtin_amdgcn_s_memrealtime();
-  if (tid < CN) {
+  if (tid < MT * CN) {
+    const int mi = tid / CN, cc = tid % CN;
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW * HS; ++w) sum += s_red[w * CN + tid];
-    const uint32_t n_out = tile * CN + (uint32_t)tid;
+    for (int w = 0; w < NW * HS; ++w) sum += s_red[(w * MT + mi) * CN + cc];
+    const uint32_t n_out = tile * CN + (uint32_t)cc;
+    const bool valid = n_out < p.n && (uint32_t)mi < p.m;
     if constexpr (SPLIT) {
       // One trip to the device coherence point, as in xbit_gemv_mfma.h: the partial sum goes into the element's 64-bit
       // accumulator as a fixed-point integer (2^-28 units, biased positive) by ONE returning atomic whose upper bits count
       // arrivals (bits 0-51 sum of (v + 2^47), 52-55 arrivals, 56-59 / 60-63 arrivals with a partial beyond +-2^19, Inf
       // or NaN); integer addition is associative, so the result does not depend on the arrival order.  The thread that
       // completes the count converts, stores and clears the slot.  Contract: include/xbitops_hip.h (split_k).
-      if (n_out < p.n) {
-        unsigned long long* slot = p.acc + (size_t)tile * (size_t)CN + (size_t)tid;
+      if (valid) {
+        unsigned long long* slot = p.acc + (size_t)tile * (size_t)(MT * CN) + (size_t)tid;
         const bool fin = __builtin_fabsf(sum) < 524288.0f;
         const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;
         const unsigned long long pos = (!fin && !(sum < 0.f)) ? (1ull << 56) : 0ull;
@@ -522,12 +568,12 @@ __global__ void __launch_bounds__(64 * NW)
           float y = (float)fixed * (1.0f / 268435456.0f);
           const bool any_pos = ((tot >> 56) & 15ull) != 0, any_neg = (tot >> 60) != 0;
           if (any_pos || any_neg) y = (any_pos && any_neg) ? __builtin_nanf("") : (any_pos ? __builtin_inff() : -__builtin_inff());
-          p.out[n_out] = as_u16((_Float16)y);
+          p.out[(size_t)mi * p.n + n_out] = as_u16((_Float16)y);
           __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     } else {
-      if (n_out < p.n) p.out[n_out] = as_u16((_Float16)sum);
+      if (valid) p.out[(size_t)mi * p.n + n_out] = as_u16((_Float16)sum);
     }
   }
   if constexpr (STAMP) {
@@ -545,30 +591,32 @@ __global__ void __launch_bounds__(64 * NW)
 // ---- host side -------------------------------------------------------------------------------------------------
 
 // LDS bytes of one workgroup (dynamic)
-inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl) {
+inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl, int mt) {
   const int hs = 16 / nl, cn = nl * cpl;
-  const size_t twice = p.g_idx != nullptr ? 2u : 1u;  // act-order: group ids beside the activations, a second table for the spliced form
-  return twice * (size_t)p.act_bytes + twice * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * cn + 3) & ~3) * 4u + 32u;
+  // act-order: group ids (2 B per k) beside the activations and a second table for the spliced form
+  const size_t ids = p.by_id ? (size_t)p.act_bytes / (size_t)mt : 0u, tables = p.by_id ? 2u : 1u;
+  return (size_t)p.act_bytes + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u + 32u;
 }
 
 constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
 constexpr int kDynWaves = 8, kDynStagers = 4, kDynLookahead = 4;
 constexpr size_t kDynMaxLds = 96u << 10;  // larger staged operands (K beyond ~24 K at g128) stay with xbit_gemv_mfma.h
+constexpr size_t kDynMaxLdsById = 156u << 10;  // act-order / odd group sizes: two table rows of 256 B per group (K = 4096 at group 16: 128 KB of them)
 
 template <int BITS>
 constexpr int dyn_ub() {
   return BITS == 2 ? 2 : 1;  // >= 3 row loads per unit
 }
 
-template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false>
+template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1>
 int launch_dyn_one(const DynParams& p, hipStream_t stream) {
   constexpr int UB = dyn_ub<BITS>();
-  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS, SPLIT, GIDX>;
+  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS, SPLIT, GIDX, MT>;
   DynParams q = p;
-  void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias,
+  void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias, &q.m,
                   &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.g_idx, &q.trace};
   return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u)), dim3(64 * kDynWaves),
-                            dyn_lds_bytes(p, NL, kDynWaves, CPL), stream, args);
+                            dyn_lds_bytes(p, NL, kDynWaves, CPL, MT), stream, args);
 }
 
 template <int BITS, int CPL, int NL, bool NT>
@@ -581,10 +629,23 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #else
   (void)stamped;
 #endif
-  if (p.g_idx != nullptr) {  // act-order: 48-column tiles, K up to 4096 (2 rounds) or 8192 (4 rounds)
+  if (p.by_id) {  // act-order: 48-column tiles, K up to 4096 (2 rounds) or 8192 (4 rounds), 1 or up to 4 rows
     if constexpr (NL == 16 && CPL == 3) {
+      if (p.m > 1u) {
+        if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 4>(p, stream);
+        if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, true, 4>(p, stream);
+        return kDynNotEligible;
+      }
       if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true>(p, stream);
       if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, true>(p, stream);
+    }
+    return kDynNotEligible;
+  }
+  if (p.m > 1u) {  // 2..4 rows: whole-K tiles of 16 lanes, K up to 4096 (2 rounds) or 8192 (4 rounds)
+    if constexpr (NL == 16) {
+      if (p.splits > 1u) return kDynNotEligible;
+      if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 4>(p, stream);
+      if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, false, 4>(p, stream);
     }
     return kDynNotEligible;
   }
@@ -604,22 +665,31 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
   return kDynNotEligible;
 }
 
-// One-row GEMV through the staged-operand kernel, or kDynNotEligible.  `cpl` / `nl`: tile shape (16 * cpl columns, or
-// nl = 8: 8 * cpl); the caller picks them.  Eligible: one activation row (any k), group size a power-of-two multiple
-// of 32 * UB, 4-byte aligned tensors, staged operands within kDynMaxLds and 8 staging rounds, every byte offset below 2^31.
+// GEMV of one to four rows through the staged-operand kernel, or kDynNotEligible.  `cpl` / `nl`: tile shape (16 * cpl
+// columns, or nl = 8: 8 * cpl); the caller picks them.  Eligible: one activation row of any length k, or up to four with
+// k % 8 == 0; any group size (power-of-two multiples of 32 * UB index the table by k-slot, the rest by computed id);
+// 4-byte aligned tensors, staged operands within kDynMaxLds and 8 staging rounds, every byte offset below 2^31.
 // `splits` >= 2 with `acc` (zeroed accumulators, one per output element of whole tiles): K is cut into that many ranges.
 template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g_idx != nullptr) {  // act-order: any ids, the "group size" only sizes nothing here; 48-column tiles, whole K
-    if (g.m != 1u || splits > 1u || nl != 16 || cpl != 3 || g.groups > 65535u || (uintptr_t)g_idx % 4u != 0u) return kDynNotEligible;
-  } else if (g.m != 1u || g.groupsize % (32u * UB) != 0u) {
-    return kDynNotEligible;
+  if (g.m < 1u || g.m > 4u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
+  // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
+  // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column
+  // tiles, whole K, every group in the LDS table.
+  const uint32_t dq = g.groupsize / (32u * UB);
+  const bool by_id = g_idx != nullptr || g.groupsize % 32u != 0u;
+  if (by_id) {
+    if (g_idx == nullptr && g.groupsize == 0u) return kDynNotEligible;
+    if (splits > 1u || g.groups > 65535u || (uintptr_t)g_idx % 4u != 0u) return kDynNotEligible;
+    cpl = 3;
+    nl = 16;
+  } else if (g.groupsize % (32u * UB) != 0u || (dq & (dq - 1u)) != 0u) {
+    return kDynNotEligible;  // multiples of 32 the table-per-k-slot scheme cannot index (96, or 32 at 2 bits): xbit_gemv_mfma.h
   }
   if (((uintptr_t)g.a | (uintptr_t)g.qweight | (uintptr_t)g.scales | (uintptr_t)g.qzeros) % 4u != 0u) return kDynNotEligible;  // dword buffer loads
-  const uint32_t d = g_idx != nullptr ? 1u : g.groupsize / (32u * UB);
-  if ((d & (d - 1u)) != 0u) return kDynNotEligible;
+  const uint32_t d = by_id ? 1u : dq;
   if (nl != 16 && !(nl == 8 && cpl == 2)) return kDynNotEligible;
   DynParams p;
   p.qweight = g.qweight;
@@ -633,10 +703,13 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   p.groups = g.groups;
   p.zw = g.zw;
   p.bias = g.bias;
+  p.m = g.m;
   p.trace = trace;
   p.g_idx = g_idx;
+  p.by_id = by_id;
   p.gshift = 0;
   while ((1u << p.gshift) < d) ++p.gshift;
+  if (by_id) p.gshift = g.groupsize;  // read only when g_idx is null: the size of the contiguous groups
   const uint32_t lk = 64u / (uint32_t)nl, kblocks = (g.k + 31u) / 32u;
   p.tiles = (g.n + (uint32_t)(nl * cpl) - 1u) / (uint32_t)(nl * cpl);
   p.units = (kblocks + lk * UB - 1u) / (lk * UB);
@@ -644,7 +717,8 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   p.ups = (p.units + p.splits - 1u) / p.splits;
   p.acc = acc;
   if (p.splits > 1u && (p.ups < 8u || (p.splits - 1u) * p.ups >= p.units)) return kDynNotEligible;  // every range holds a unit for every wave
-  p.act_bytes = p.ups * lk * UB * 64u;
+  const uint32_t mt = g.m > 1u ? 4u : 1u;
+  p.act_bytes = p.ups * lk * UB * 64u * mt;
   // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
   // launches cover at least `groups` rows so that the zero rows past the last group exist
   p.tab_groups = ((p.ups * lk - 1u + ((1u << p.gshift) - 1u)) >> p.gshift) + 1u;
@@ -652,15 +726,16 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
     p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
     if (p.tab_groups < p.groups) p.tab_groups = p.groups;
   }
-  if (g_idx != nullptr) p.tab_groups = p.groups;  // every group, whatever K
-  if (dyn_lds_bytes(p, nl, kDynWaves, cpl) > kDynMaxLds) return kDynNotEligible;
+  if (by_id) p.tab_groups = p.groups;  // every group, whatever K
+  if (dyn_lds_bytes(p, nl, kDynWaves, cpl, (int)mt) > (by_id ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
   if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
   constexpr uint32_t st = 64u * kDynStagers;
-  const uint32_t chunks = p.act_bytes / (uint32_t)(Unpack<BITS>::kChunkK * 2);
+  const uint32_t chunks = p.act_bytes / mt / (uint32_t)(Unpack<BITS>::kChunkK * 2);  // a staging thread takes one chunk of every row per round
   const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
-  const uint32_t r_gid = g_idx != nullptr ? (p.act_bytes / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round
-  const uint32_t rounds = r_act > r_tab ? (r_act > r_gid ? r_act : r_gid) : (r_tab > r_gid ? r_tab : r_gid);
+  const uint32_t r_gid = by_id ? (p.act_bytes / mt / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round
+  const uint32_t r_tab_static = by_id ? 0u : r_tab;  // the by-id build stages table entries beyond its static rounds in a loop
+  const uint32_t rounds = r_act > r_tab_static ? (r_act > r_gid ? r_act : r_gid) : (r_tab_static > r_gid ? r_tab_static : r_gid);
 #define XBIT_DYN(CPL_, NL_)                                                                      \
   return nt ? launch_dyn_si<BITS, CPL_, NL_, true>(p, stream, rounds, stamped)                   \
             : launch_dyn_si<BITS, CPL_, NL_, XBIT_TUNING ? false : true>(p, stream, rounds, stamped)

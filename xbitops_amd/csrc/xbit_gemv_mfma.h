@@ -70,11 +70,11 @@ struct LoadSchedule {
 };
 
 // CPL adjacent packed words of one row (8 / 12 / 16 bytes per lane)
-template <int CPL, bool NT, int AUXX = 0>
+template <int CPL, bool NT>
 struct RowLoad {
   uint32_t v[CPL];
   __device__ __forceinline__ void load(rsrc_t r, uint32_t voff, uint32_t soff) {
-    constexpr int aux = (NT ? 2 : 0) | AUXX;  // nt: read-once stream; AUXX (measurement builds): 1 = sc0, 16 = sc1
+    constexpr int aux = NT ? 2 : 0;  // nt: read-once stream
     if constexpr (CPL == 2) {
       const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux);
       v[0] = t.x; v[1] = t.y;
@@ -100,18 +100,19 @@ struct RowLoad {
 //         block carries zeros in the other set's octets (512 contiguous bytes per row and instruction).
 //   NW    waves per workgroup        MT   activation rows per pass (<= NL)
 //   NT    nontemporal weight loads   GUARD  false when the shape needs no edge handling at all
-//   ABLATE (measurement builds only): 1 = no weight loads (registers stand in), 2 = no
-//          unpack/dequant/MFMA (loaded words are xor-folded), 3 = both (all three: wrong results);
-//          4 = correct results, always the spliced (pre-subnormal) unpack, for A/B timing;
-//          16 = correct results (M = 1), multiply-accumulate on the VALU (v_dot2_f32_f16 + shuffles) instead of the MFMA;
-//          8 = correct results plus per-wave s_memrealtime stamps written to p.trace;
-//          32 / 64 / 128 = no activation loads / no scale + zero loads / no cross-wave reduction; 256 / 512 = sc1 / sc0 on
-//          the weight loads; 1024 = first weight rows ahead of the small operands; 2048 / 4096 = addresses of a
-//          tile-contiguous layout / with a (scale | -z*s) row per batch (wrong results); 8192 / 16384 = activation
-//          slice of an 8-16 row pass staged in 4 / 2 parts; 32768 / 65536 = other forms of the reduction reads;
-//          131072 = wait for a step's rows before issuing the next; 262144 = extra workgroups touch the next call's
-//          weights; 524288 = a line-requesting helper wave per workgroup.  All of them: XBIT_TUNING builds only,
-//          each with its measurement under profiles/ (DESIGN.md section 4).
+//   ABLATE (measurement builds only; every one of them computes the production results):
+//          4 = always the spliced (pre-subnormal) unpack, for A/B timing;
+//          8 = per-wave s_memrealtime stamps written to p.trace;
+//          16 = (M = 1) multiply-accumulate on the VALU (v_dot2_f32_f16 + shuffles) instead of the MFMA;
+//          1024 = first weight rows ahead of the small operands;
+//          8192 / 16384 = activation slice of an 8-16 row pass staged in 4 / 2 parts;
+//          32768 / 65536 = other forms of the reduction reads;
+//          131072 = wait for a step's rows before issuing the next.
+//          XBIT_TUNING builds only, each with its measurement under profiles/ (DESIGN.md section 4).  The probes that
+//          did NOT compute the GEMV (loads-only and no-operand ablations, cache-policy bits, tile-contiguous address
+//          streams, next-call prefetch workgroups, helper waves, the integer-domain instruction mix) lived here in
+//          rounds 1-2; their results are in profiles/r01 and profiles/r02, their code in the history (tools/README.md),
+//          and such experiments now go to tools/microbench/gemv_lab.hip, outside the library.
 //   LA   load lookahead in row loads (0 = issue the whole batch up front).  A wave issues in order,
 //        and the CU's memory pipeline back-pressures: a wave that queues all its loads first sits at
 //        the last load instruction until the queue drains and only then starts on data that came
@@ -133,8 +134,6 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
   constexpr bool WAITFIRST = (ABLATE & 131072) != 0;
-  constexpr bool PACKED_PROBE = (ABLATE & 2048) != 0;
-  constexpr bool PROBE_META = (ABLATE & 4096) != 0;
   constexpr bool WFIRST = (ABLATE & 1024) != 0;  // measurement: first weight rows issued ahead of the activation slice
   constexpr int LK = 64 / NL;                // k-slots per wave
   constexpr int RS = NL < 16 ? 16 / NL : 1;  // NL = 8: k-slots sharing one MFMA k-octet (in different column slots)
@@ -179,49 +178,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   float* const s_red = reinterpret_cast<float*>(s_lds + (ALIAS ? 0 : NW * ACT_DW));
 
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kl = lane / NL, nl = lane % NL;
-  // HELPER (measurement build 524288): the workgroup's LAST wave computes nothing; it requests one dword of every
-  // 128-byte line of the tile, in the order the compute waves consume the packed rows, so that HBM -> L2 runs at
-  // the rate of a dependence-free read while the compute waves' own loads find their lines in (or on the way to) L2
-  constexpr bool HELPER = (ABLATE & 524288) != 0;
-  const int nwaves = (int)(blockDim.x >> 6) - (HELPER ? 1 : 0);   // compute waves, <= NW
-  const bool helper = HELPER && wv == nwaves;
-  if constexpr (ABLATE & 262144) {
-    // Prototype (measurement build): 256 more workgroups in the grid touch one dword of every 128-byte line of the
-    // NEXT call's packed weights (p.acc, same shape) while this call computes, so that the next call finds them in
-    // L2 / the Infinity Cache.  Workgroup (XCD x = blockIdx & 7, j of 32) takes rows [j*kw/32, (j+1)*kw/32) of the
-    // column stripe that XCD x's tiles cover - the lines land in the L2 that will read them.
-    if (blockIdx.x >= p.tiles) {
-      const uint32_t pb = blockIdx.x - p.tiles, x = blockIdx.x & 7u, j = pb >> 3;
-      const uint32_t q = p.tiles >> 3, r = p.tiles & 7u;
-      const uint32_t t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1u : 0u);
-      const uint32_t row_b = p.n * 4u, lo = (t0 * (uint32_t)(NL * CPL) * 4u) & ~127u;
-      uint32_t hi = (t0 + cnt) * (uint32_t)(NL * CPL) * 4u;
-      hi = hi < row_b ? hi : row_b;
-      const uint32_t lpr = hi > lo ? (hi - lo + 127u) / 128u : 0u;
-      const uint32_t r0 = (uint32_t)(((uint64_t)j * p.kw) / 32u), r1 = (uint32_t)(((uint64_t)(j + 1) * p.kw) / 32u);
-      const rsrc_t r_pf = make_rsrc(p.acc, p.kw * row_b);
-      uint32_t sum = 0;
-      if ((p.bps & 255u) == 2u) {  // flat: workgroup pb reads its 1/256 of the bytes, 16 B per lane, contiguous (no XCD affinity)
-        const uint32_t total16 = (p.kw * row_b) / 16u, per = (total16 + 255u) / 256u;
-        for (uint32_t i = (uint32_t)tid; i < per; i += blockDim.x) {
-          const uint32_t e = pb * per + i;
-          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r_pf, e < total16 ? e * 16u : kOob, 0, 0);
-          sum ^= v.x ^ v.y ^ v.z ^ v.w;
-        }
-      } else {
-        // pacing: wave w of the prefetch workgroup starts w * (p.bps >> 8) * 64 clocks late, so the 22 MB of line
-        // requests are spread over the launch instead of filling every memory queue in its first microsecond
-        for (uint32_t d = 0; d < (uint32_t)wv * (p.bps >> 8); ++d) __builtin_amdgcn_s_sleep(1);
-        for (uint32_t idx = (uint32_t)tid; idx < (r1 - r0) * lpr; idx += blockDim.x) {
-          const uint32_t off = (r0 + idx / lpr) * row_b + lo + (idx % lpr) * 128u;
-          sum ^= __builtin_amdgcn_raw_buffer_load_b32(r_pf, off, 0, 0);
-        }
-      }
-      asm volatile("" ::"v"(sum));
-      return;
-    }
-    if (p.splits == 7u) return;  // measurement: the prefetch workgroups alone
-  }
+  const int nwaves = (int)(blockDim.x >> 6);  // <= NW
   const uint32_t T = (uint32_t)(LK * nwaves);  // k-batches per workgroup sweep
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
   const uint32_t tile_g = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);  // tile of the whole grid
@@ -267,7 +224,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const uint32_t row_bytes = n_ * 4u;  // one packed row
 
-  const rsrc_t r_w = make_rsrc(qweight_, PACKED_PROBE ? (p.kw + p.kw / 8u) * row_bytes : p.kw * row_bytes);  // probe: tools/gemv_sweep.py allocates the slack
+  const rsrc_t r_w = make_rsrc(qweight_, p.kw * row_bytes);
   const rsrc_t r_s = make_rsrc(scales_, p.groups * n_ * 2u);
   const rsrc_t r_z = make_rsrc(qzeros_, p.groups * zw_ * 4u);
   const rsrc_t r_a = make_rsrc(p.a, p.m * p.k * 2u);
@@ -278,51 +235,22 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABLATE & 8) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
-  if constexpr (HELPER) {
-    if (helper) {
-      // instruction i of batch group g: lane (b = lane >> 1, h = lane & 1) touches line h of packed row (g*32 + b)*UB*BITS + i
-      const uint32_t lo = (tile * (uint32_t)(CN * 4)) & ~127u;
-      uint32_t sum = 0;
-      for (uint32_t g0 = b_begin; g0 < b_end; g0 += 32u) {
-        const uint32_t bb = g0 + (uint32_t)(lane >> 1);
-        const uint32_t base = bb < b_end ? bb * (uint32_t)(UB * BITS) * row_bytes + lo + (uint32_t)(lane & 1) * 128u : kOob;
-#pragma unroll
-        for (int i = 0; i < UB * BITS; ++i) sum ^= __builtin_amdgcn_raw_buffer_load_b32(r_w, base, (uint32_t)i * row_bytes, 0);
-      }
-      asm volatile("" ::"v"(sum));
-    }
-  }
-  for (uint32_t b0 = helper ? b_end : b_begin; b0 < b_end; b0 += T) {
+  for (uint32_t b0 = b_begin; b0 < b_end; b0 += T) {
     const uint32_t wb = b0 + wv * LK;  // first batch of this wave in this sweep
     const uint32_t bt = wb + kl;       // this lane's batch
     const bool active = GUARD ? (col_ok && bt < b_end) : true;
 
     // (3) all packed-weight loads of this lane's batch: one 32-bit lane offset, the row step rides in
     //     the scalar offset.  Rows past the end of qweight read 0 (their activations are 0 as well).
-    RowLoad<CPL, NT, ((ABLATE & 256) ? 16 : 0) | ((ABLATE & 512) ? 1 : 0)> w[UB][BITS];
+    RowLoad<CPL, NT> w[UB][BITS];
     uint32_t lane_off = (bt * (uint32_t)(UB * BITS)) * row_bytes + col * 4u;
-    // measurement (wrong results): the addresses a tile-contiguous layout [tile][wave batch group][row][k-slot][cw columns]
-    // would have; cw (p.splits) = real columns per tile <= CN, PROBE_META: one more row per batch holding (scale | -z*s)
-    constexpr uint32_t PROBE_R = (uint32_t)(UB * BITS + (PROBE_META ? 1 : 0));
-    const uint32_t cw = PACKED_PROBE ? p.splits : (uint32_t)CN;
-    if constexpr (PACKED_PROBE) {
-      lane_off = tile * (((p.batches + LK - 1) / LK) * PROBE_R * LK * cw * 4u) + (((wb / LK) * (PROBE_R * LK) + (uint32_t)kl) * cw + (uint32_t)(nl * CPL)) * 4u;
-      if ((uint32_t)(nl * CPL) >= cw) lane_off = kOob;
-    }
     if (GUARD && !active) lane_off = kOob;
-    RowLoad<CPL, NT, 0> probe_meta;
-    if constexpr (PROBE_META) probe_meta.load(r_w, lane_off, 0);
     using LS = LoadSchedule<BITS, UB, LA>;
     auto issue_range = [&](auto from_c, auto to_c) {
       constexpr int from = decltype(from_c)::value, to = decltype(to_c)::value;
       static_for<(to > from ? to - from : 0)>([&](auto d) {
         constexpr int idx = from + decltype(d)::value, j = idx / BITS, i = idx % BITS;
-        if constexpr (ABLATE & 1) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) w[j][i].v[c] = lane_off * (uint32_t)(2 * c + 3) + (uint32_t)idx * 0x9E3779B1u;
-        } else {
-          w[j][i].load(r_w, lane_off, PACKED_PROBE ? (uint32_t)(idx + (PROBE_META ? 1 : 0)) * (uint32_t)(LK * 4) * cw : (uint32_t)idx * row_bytes);
-        }
+        w[j][i].load(r_w, lane_off, (uint32_t)idx * row_bytes);
       });
     };
     if constexpr (WFIRST) {
@@ -356,8 +284,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
         for (int q = 0; q < CPT; ++q) {
           uint32_t o = aoff + 16u * q;
           if (GUARD && CPT > 1 && k0 + 8u * q >= k_end) o = kOob;
-          if constexpr (ABLATE & 32) hraw[part][r][q] = u32x4_t{o, o + 1u, o + 2u, o + 3u};  // measurement: no activation loads
-          else hraw[part][r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
+          hraw[part][r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, o, 0, 0);
         }
       }
     };
@@ -372,15 +299,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       const uint32_t h0 = gi * n_ + col;
       uint32_t soff = (h0 & ~1u) * 2u;
       if (GUARD && !active) soff = kOob;
-      if constexpr (PROBE_META) {
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) sbits[c] = 0x1C00u | (probe_meta.v[c] & 0x3FFu);
-      } else if constexpr (ABLATE & 64) {  // measurement: no scale loads
-        sbits[0] = 0x1C00u + (soff & 0xFFu);
-        sbits[1] = sbits[0] + 1u;
-        if constexpr (CPL > 2) sbits[2] = sbits[0] + 2u;
-        if constexpr (CPL > 3) sbits[3] = sbits[0] + 3u;
-      } else if constexpr (CPL == 2) {  // col and n are even: h0 is even
+      if constexpr (CPL == 2) {  // col and n are even: h0 is even
         const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r_s, soff, 0, 0);
         sbits[0] = v & 0xFFFFu;
         sbits[1] = v >> 16;
@@ -398,11 +317,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
     {
       const uint32_t bit = col * BITS, sh = bit & 31u;
       const uint32_t zoff = (gi * zw_ + (bit >> 5)) * 4u;
-      if constexpr (PROBE_META) {
-        zwin = probe_meta.v[CPL - 1] >> 16;
-      } else if constexpr (ABLATE & 64) {
-        zwin = zoff >> sh;  // measurement: no zero-point loads
-      } else if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
+      if constexpr (CPL * BITS <= 32 && (32 % (CPL * BITS)) == 0) {
         zwin = __builtin_amdgcn_raw_buffer_load_b32(r_z, zoff, 0, 0) >> sh;  // the CPL fields never straddle a word
       } else {
         const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_z, zoff, 0, 0);  // a read past the row end is harmless
@@ -450,8 +365,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
                                  ((uint32_t)(4 + 2 * (khi & 1)) << 16) | ((uint32_t)(5 + 2 * (khi & 1)) << 24);
             o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
           }
-          if constexpr (!(ABLATE & 32)) *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
-          else asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+          *reinterpret_cast<u32x4_t*>(dst + 4 * q) = u32x4_t{o[0], o[1], o[2], o[3]};
         }
       }
       // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
@@ -514,48 +428,34 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
 #pragma unroll
           for (int i = 0; i < BITS; ++i) wc[c][i] = w[j][i].v[c];
 
-        if constexpr (ABLATE & 2) {
-          if constexpr (oct == 0) {
+        const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + a_off + j * 16 + 4 * oct);
+        const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
+        u32x4_t braw[CPL];
+        static_for<4>([&](auto e_c) {
+          constexpr int e = decltype(e_c)::value;
+          constexpr int pr = 4 * oct + e;
+          uint32_t Q[CPL];
+          if constexpr (FAST) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c)
+            for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template sub_pair<pr>(wc[c], sub_mask);
 #pragma unroll
-              for (int i = 0; i < BITS; ++i) acc[c][0] += __builtin_bit_cast(float, wc[c][i] & 0x3FFFFFFFu);
-          }
-        } else {
-          const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(my_act + a_off + j * 16 + 4 * oct);
-          const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
-          u32x4_t braw[CPL];
-          static_for<4>([&](auto e_c) {
-            constexpr int e = decltype(e_c)::value;
-            constexpr int pr = 4 * oct + e;
-            uint32_t Q[CPL];
-            if constexpr (ABLATE & 1048576) {
-              // measurement (wrong results): the instruction mix of an integer-domain multiply - one v_and_or_b32 per
-              // pair (1024 + q * 2^e straight into the MFMA), one shift per word, no packed FMA
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) braw[c][e] = Unpack<BITS>::template pair<pr>(wc[c], uk);
-            } else if constexpr (FAST) {
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template sub_pair<pr>(wc[c], sub_mask);
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(__builtin_elementwise_fma(as_h2(Q[c]), ss2[c], nzs2[c]));
-            } else {
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template pair<pr>(wc[c], uk);
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]));
-            }
-          });
-          if constexpr (ABLATE & 16) {  // measurement: the same W pairs accumulated on the VALU (v_dot2_f32_f16), M = 1
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) acc[c][0] = __builtin_amdgcn_fdot2(as_h2(braw[c][e]), as_h2(araw[e]), acc[c][0], false);
+            for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(__builtin_elementwise_fma(as_h2(Q[c]), ss2[c], nzs2[c]));
           } else {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c)
-              acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+            for (int c = 0; c < CPL; ++c) Q[c] = Unpack<BITS>::template pair<pr>(wc[c], uk);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) braw[c][e] = as_u32(dequant_pair<Unpack<BITS>::pair_exp(pr)>(Q[c], s2[c], nzs2[c]));
           }
+        });
+        if constexpr (ABLATE & 16) {  // measurement: the same W pairs accumulated on the VALU (v_dot2_f32_f16), M = 1
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c][0] = __builtin_amdgcn_fdot2(as_h2(braw[c][e]), as_h2(araw[e]), acc[c][0], false);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
         }
         if constexpr (LA > 0) __builtin_amdgcn_sched_barrier(0);
       });
@@ -583,17 +483,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
       acc[c][0] = v;
     }
   }
-  if constexpr (ABLATE & 128) {  // measurement: no cross-wave reduction, every lane stores something
-    float v = 0.f;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) v += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
-    if (col_ok) out_[(tile * CN + (uint32_t)(tid % CN)) % n_] = as_u16((_Float16)v);
-    return;
-  }
   if constexpr (ALIAS) __syncthreads();  // every wave is done reading its activations
   // D[drow][slot]: drow = 4*(lane>>4) + r lives in register r of lane (lane>>4, slot = lane&15).
   // Keep the quadrant where the row block equals the slot's k-slot, then sum over k-slots and waves.
-  if (!helper) {
+  {
     const int slot = lane & 15, ks = slot / NL, snl = slot % NL;
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
@@ -805,6 +698,10 @@ inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int 
     plan.cpl = 4;
     plan.splits = (uint32_t)forced_splits < 15u ? (uint32_t)forced_splits : 15u;
     if (plan.splits > batches / 8u) plan.splits = batches / 8u;
+    if (plan.splits >= 2u) {  // no empty K ranges: 121 batches in 15 ranges of 9 leave the last one without work - 14 ranges then
+      const uint32_t bps = (batches + plan.splits - 1u) / plan.splits;
+      plan.splits = (batches + bps - 1u) / bps;
+    }
     if (plan.splits < 2u) plan.splits = 0;
     return plan;
   }
@@ -848,43 +745,6 @@ int launch_la(GemvParams p, hipStream_t stream) {
   p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
   dim3 grid(p.tiles, p.m), block(64 * NW);
   return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
-}
-
-// measurement-only: tile-contiguous address probe, `cw` real columns per tile (0 = the full 16*CPL)
-template <int BITS, int UB, int CPL, int NL, int NW, int ABLATE, int LA>
-int launch_probe(GemvParams p, hipStream_t stream, uint32_t cw) {
-  constexpr int CN = NL * CPL;
-  p.splits = cw ? cw : (uint32_t)CN;
-  p.tiles = (p.n + p.splits - 1) / p.splits;
-  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  if ((uint64_t)p.tiles * CN > p.n + 4096u) return XBIT_ERR_SHAPE;
-  dim3 grid(p.tiles, p.m), block(64 * NW);
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, ABLATE, LA>, grid, block, stream, p);
-}
-
-// measurement-only: the production M = 1 launch with one more wave per workgroup that only requests the tile's lines
-template <int BITS, int UB, int CPL, int NL, int NW, int ABLATE, int LA>
-int launch_helper(GemvParams p, hipStream_t stream) {
-  constexpr int CN = NL * CPL;
-  p.tiles = (p.n + CN - 1) / CN;
-  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  const uint32_t waves = sweep_waves(p.batches, 64 / NL, NW);
-  dim3 grid(p.tiles, p.m), block(64 * (waves + 1));
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW + 1, 1, false, true, ABLATE | 524288, LA>, grid, block, stream, p);
-}
-
-// measurement-only: the production M = 1 launch plus 256 prefetch workgroups for the next call's weights (opts.user_ws)
-template <int BITS, int UB, int CPL, int NL, int NW, int LA>
-int launch_with_prefetch(GemvParams p, hipStream_t stream, const GemvLaunchOpts& opts, uint32_t only = 0, uint32_t flat = 0, uint32_t pace = 0) {
-  constexpr int CN = NL * CPL;
-  if (opts.user_ws == nullptr) return XBIT_ERR_NULL_POINTER;
-  p.tiles = (p.n + CN - 1) / CN;
-  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  p.acc = opts.user_ws;
-  p.splits = only ? 7u : 0u;
-  p.bps = (flat ? 2u : 0u) | (pace << 8);
-  dim3 grid(p.tiles + 256u, p.m), block(64 * NW);
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, NL, NW, 1, false, true, 262144, LA>, grid, block, stream, p);
 }
 
 // measurement-only launch of the 16-row pass (NL = 16, 8 waves) with ABLATE bits
@@ -1035,7 +895,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
   // 399 never (the whole-K kernels of this file, unsplit, for A/B), 398 never, but with this file's own launch rules (split-K
   // included): the round-2 library.
   auto try_dyn = [&](int auto_cpl, bool auto_small_n) -> int {
-    if (p.m != 1u) return kGemvDynNotEligible;
+    if (p.m > 4u) return kGemvDynNotEligible;
+    if (p.m > 1u && (auto_small_n || !(BITS == 4 || BITS == 8)) && !(XBIT_TUNING && variant >= 300))
+      return kGemvDynNotEligible;  // the 16-column tiles take one row; 2-4 rows pay at 4 and 8 bits only (rule below)
     int dcpl = auto_small_n ? 2 : auto_cpl, dnl = auto_small_n ? 8 : 16;
     bool nt = true, stamped = false;
 #if XBIT_TUNING
@@ -1052,21 +914,13 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
 #if XBIT_TUNING
     if (variant == 180 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 1024>(p, stream);  // 16-row pass, weights first
     if (variant == 181 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 0>(p, stream);     // same launch, production order
-    if (variant == 182 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32>(p, stream);    // no activation staging at all (wrong results): the floor
-    if (variant == 184 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32 | 128>(p, stream);      // ... and no LDS reduction
-    if (variant == 185 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2 | 32 | 128>(p, stream);  // ... and no arithmetic: loads only
-    if (variant == 186 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 128>(p, stream);           // full kernel minus the LDS reduction
     if (variant == 189 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8>(p, stream);             // stamped (tools/gemv_trace.py --m 16)
     if (variant == 193 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 8, 4>(p, stream);  // 4-row pass, stamped
-    if (variant == 194 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 2 | 32 | 128, 4>(p, stream);  // 4-row pass, loads only
-    if (variant == 195 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 128, 4>(p, stream);  // 4-row pass minus the LDS reduction
-    if (variant == 196 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 32, 4>(p, stream);   // 4-row pass minus the activation loads
     if (variant == 198 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 16384 | 32768>(p, stream);  // ... and the reduction reads unrolled and predicated
     if (variant == 199 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32768>(p, stream);          // whole slice, reduction reads unrolled and predicated
     if (variant == 200 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 65536>(p, stream);         // whole slice, reduction reads unconditional + select
     if (variant == 197 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 16384>(p, stream);         // activation slice in two parts (k-blocks 0-1, 2-3), the second behind the first weight rows
     if (variant == 188 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8192>(p, stream);          // activation slice fetched and staged k-block by k-block inside the step loop
-    if (variant == 187 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 2048>(p, stream);          // tile-contiguous addresses (wrong results)
     if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
       switch (variant) {
         case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
@@ -1099,15 +953,8 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 17: return launch_m1<BITS, 4, 3, 16, 8, false, 2>(p, stream);
           case 18: return launch_m1<BITS, 4, 3, 16, 8, false, 6>(p, stream);
           case 19: return launch_m1<BITS, 4, 3, 16, 8, false, 8>(p, stream);
-          case 31: return launch_la<BITS, 4, 3, 16, 8, 1, kLookahead>(p, stream);  // no weight loads
-          case 32: return launch_la<BITS, 4, 3, 16, 8, 2, kLookahead>(p, stream);  // loads only
-          case 33: return launch_la<BITS, 4, 3, 16, 8, 3, kLookahead>(p, stream);  // neither
-          case 46: return launch_la<BITS, 4, 4, 16, 8, 1, kLookahead>(p, stream);
-          case 47: return launch_la<BITS, 4, 4, 16, 8, 2, kLookahead>(p, stream);
           case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);  // stamped (tools/gemv_trace.py)
           case 64: return launch_la<BITS, 4, 3, 16, 8, 16, kLookahead>(p, stream);  // VALU accumulate (v_dot2) instead of MFMA
-          // round-2 experiments: loads-only builds at other lookaheads, full builds at LA 5 / 12, 16 waves at deeper LA
-          case 131: return launch_la<BITS, 4, 3, 16, 8, 2, 0>(p, stream);
           case 183: return launch_la<BITS, 4, 3, 16, 8, 1024, 4>(p, stream);     // M = 1, first weight rows ahead of the small operands
           case 190: return launch_m1<BITS, 2, 4, 8, 8, false>(p, stream);   // 32-column tiles as 8 lanes x 16 B x 8 k-slots (1 KB per instruction), 2 k-blocks per lane
           case 191: return launch_m1<BITS, 1, 4, 8, 8, false>(p, stream);   // ... 1 k-block per lane
@@ -1120,13 +967,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 175: return launch_m1<BITS, 4, 3, 16, 8, false, 128>(p, stream);   // 2 -> 8
           case 176: return launch_m1<BITS, 4, 4, 16, 8, false, 138>(p, stream);   // 64-column tiles, 3 -> 8
           case 177: return launch_m1<BITS, 4, 4, 16, 8, false, 126>(p, stream);   // 64-column tiles, 2 -> 6
-          case 160: return launch_la<BITS, 4, 3, 16, 8, 256, 4>(p, stream);         // weight loads sc1 (L1 bypass?)
-          case 161: return launch_la<BITS, 4, 3, 16, 8, 256 | 512, 4>(p, stream);   // sc0 sc1
-          case 162: return launch_la<BITS, 4, 3, 16, 8, 256, 8>(p, stream);         // sc1, lookahead 8
-          case 163: return launch_la<BITS, 4, 3, 16, 8, 256 | 512, 8>(p, stream);   // sc0 sc1, lookahead 8
           case 164: return launch_m1<BITS, 4, 3, 16, 8, true, 8>(p, stream);        // nt, lookahead 8
-          case 165: return launch_la<BITS, 4, 3, 16, 8, 256, 6>(p, stream);         // sc1, lookahead 6
-          case 166: return launch_la<BITS, 4, 3, 16, 8, 512, 6>(p, stream);         // sc0, lookahead 6
           // 128-column tiles (the 8192x28672 path: 32 lanes x 16 B, nontemporal): lookahead and workgroup size
           case 236: return launch_m1<BITS, 4, 4, 32, 16, true, 2>(p, stream);
           case 237: return launch_m1<BITS, 4, 4, 32, 16, true, 6>(p, stream);
@@ -1136,24 +977,8 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 241: return launch_m1<BITS, 4, 4, 32, 8, true, 8>(p, stream);
           case 242: return launch_m1<BITS, 4, 4, 16, 8, true, 6>(p, stream);   // 64-column tiles, nontemporal, lookahead 6
           case 243: return launch_m1<BITS, 4, 4, 16, 8, true, 8>(p, stream);
-          case 270: return launch_la<BITS, 4, 3, 16, 8, 1048576, 4>(p, stream);   // integer-domain instruction mix (wrong results), 48-column tiles
-          case 271: return launch_la<BITS, 4, 4, 16, 8, 1048576, 4>(p, stream);   // ... 64-column tiles, 8 waves
-          case 272: return launch_la<BITS, 4, 4, 16, 8, 0, 4>(p, stream);         // reference for 271: the same launch, exact arithmetic
-          case 273: return launch_la<BITS, 4, 4, 32, 16, 1048576, 4>(p, stream);  // 128-column tiles, 16 waves (the 8192x28672 shape; plain loads)
-          case 274: return launch_la<BITS, 4, 4, 32, 16, 0, 4>(p, stream);        // reference for 273
-          case 260: return launch_helper<BITS, 4, 3, 16, 8, 0, 4>(p, stream);    // + one line-requesting helper wave per workgroup
-          case 261: return launch_helper<BITS, 4, 3, 16, 8, 0, 2>(p, stream);    // ... lookahead 2
-          case 262: return launch_helper<BITS, 4, 3, 16, 8, 0, 6>(p, stream);
-          case 263: return launch_helper<BITS, 4, 3, 16, 8, 2, 4>(p, stream);    // ... loads only
-          case 264: return launch_helper<BITS, 4, 4, 16, 8, 0, 4>(p, stream);    // 64-column tiles
-          case 250: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts);  // + prefetch workgroups for the next call's weights
-          case 255: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 0, 10);  // paced: wave w starts w * 640 clocks late
-          case 256: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 0, 20);  // ... w * 1280 clocks
-          case 257: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 0, 30);
-          case 258: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 1, 0, 20);  // paced, alone
-          case 251: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 1, 0);  // the prefetch workgroups alone (line touches, XCD stripes)
-          case 252: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 0, 1);  // flat 16-byte reads instead of line touches
-          case 253: return launch_with_prefetch<BITS, 4, 3, 16, 8, 4>(p, stream, opts, 1, 1);  // ... alone
+          case 272: return launch_la<BITS, 4, 4, 16, 8, 0, 4>(p, stream);         // 64-column tiles, 8 waves, lookahead 4
+          case 274: return launch_la<BITS, 4, 4, 32, 16, 0, 4>(p, stream);        // 128-column tiles, 16 waves, plain loads
           case 231: return launch_la<BITS, 4, 3, 16, 8, 131072, 4>(p, stream);  // wait for a step's rows before issuing the next loads, lookahead 4
           case 232: return launch_la<BITS, 4, 3, 16, 8, 131072, 5>(p, stream);  // ... lookahead 5 (the same 5 rows outstanding at most)
           case 233: return launch_la<BITS, 4, 3, 16, 8, 131072, 6>(p, stream);
@@ -1161,47 +986,13 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
           case 235: return launch_la<BITS, 4, 3, 16, 8, 0, 5>(p, stream);       // lookahead 5, production order
           case 230: return launch_la<BITS, 4, 3, 16, 8, 65536, 4>(p, stream);   // reduction reads unconditional + select
           case 229: return launch_la<BITS, 4, 3, 16, 8, 32768, 4>(p, stream);   // reduction reads unrolled and predicated
-          case 210: return launch_probe<BITS, 4, 3, 16, 8, 2048, 4>(p, stream, 0);        // tile-contiguous addresses (wrong results), 48-column tiles
-          case 211: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 64, 4>(p, stream, 0);   // ... and no scale / zero loads
-          case 212: return launch_probe<BITS, 4, 4, 16, 8, 2048, 4>(p, stream, 0);        // ... 64-column tiles
-          case 213: return launch_probe<BITS, 2, 2, 8, 8, 2048, 4>(p, stream, 0);         // ... 16-column tiles (8 lanes x 8 B x 8 k-slots), whole K
-          case 214: return launch_la<BITS, 2, 2, 8, 8, 0, 4>(p, stream);                  // the same tiles in the reference layout
-          case 215: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 2, 4>(p, stream, 0);    // tile-contiguous, loads only
-          case 216: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 2 | 32 | 64 | 128, 0>(p, stream, 0);  // ... none of the small operands, all loads up front
-          case 218: return launch_probe<BITS, 4, 3, 16, 8, 2048, 6>(p, stream, 0);        // lookahead 6
-          case 219: return launch_probe<BITS, 4, 3, 16, 8, 2048, 3>(p, stream, 0);        // lookahead 3
-          // ... with the scale and -z*s of a batch as one more row of the stream (no separate scale / zero loads)
-          case 220: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 4>(p, stream, 0);
-          // ... and tiles of n/256 real columns, one per CU (4096x11008: 43 columns)
-          case 221: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 4>(p, stream, (p.n + 255u) / 256u);
-          case 222: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 64, 4>(p, stream, (p.n + 255u) / 256u);
-          case 223: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 5>(p, stream, (p.n + 255u) / 256u);
-          case 224: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64, 6>(p, stream, (p.n + 255u) / 256u);
-          case 225: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64 | 2, 4>(p, stream, (p.n + 255u) / 256u);  // loads only
-          case 226: return launch_probe<BITS, 4, 3, 16, 8, 2048 | 4096 | 64 | 2 | 32 | 128, 0>(p, stream, (p.n + 255u) / 256u);  // pure stream
-          // 16-slot tiles (8 lanes x 8 B x 8 k-slots) of n/256 real columns (8192x3584: 14, 4096x4096: 16), whole K
-          case 227: return launch_probe<BITS, 2, 2, 8, 8, 2048 | 4096 | 64, 4>(p, stream, (p.n + 255u) / 256u);
-          case 228: return launch_probe<BITS, 2, 2, 8, 8, 2048 | 4096 | 64, 6>(p, stream, (p.n + 255u) / 256u);
-          case 150: return launch_la<BITS, 4, 3, 16, 8, 2 | 32, 4>(p, stream);              // loads only, no activation staging
-          case 151: return launch_la<BITS, 4, 3, 16, 8, 2 | 64, 4>(p, stream);              // loads only, no scale / zero loads
-          case 152: return launch_la<BITS, 4, 3, 16, 8, 2 | 128, 4>(p, stream);             // loads only, no LDS reduction
-          case 153: return launch_la<BITS, 4, 3, 16, 8, 2 | 32 | 64 | 128, 4>(p, stream);   // loads only, none of the three
-          case 154: return launch_la<BITS, 4, 3, 16, 8, 2 | 32 | 64 | 128, 0>(p, stream);   // ... all loads up front
-          case 155: return launch_la<BITS, 4, 3, 16, 8, 32 | 64 | 128, 4>(p, stream);       // arithmetic kept, none of the three
-          case 156: return launch_la<BITS, 4, 3, 16, 8, 128, 4>(p, stream);                 // full kernel minus the LDS reduction
-          case 157: return launch_la<BITS, 4, 3, 16, 8, 32, 4>(p, stream);                  // full kernel minus activation staging
-          case 158: return launch_la<BITS, 4, 3, 16, 8, 64, 4>(p, stream);                  // full kernel minus scale / zero loads
-          case 132: return launch_la<BITS, 4, 3, 16, 8, 2, 6>(p, stream);
-          case 133: return launch_la<BITS, 4, 3, 16, 8, 2, 8>(p, stream);
-          case 134: return launch_la<BITS, 4, 3, 16, 8, 2, 12>(p, stream);
+          case 214: return launch_la<BITS, 2, 2, 8, 8, 0, 4>(p, stream);   // 16-column tiles (8 lanes x 8 B x 8 k-slots), whole K
           case 135: return launch_m1<BITS, 4, 3, 16, 8, false, 5>(p, stream);
           case 136: return launch_m1<BITS, 4, 4, 16, 8, false, 6>(p, stream);
           case 137: return launch_m1<BITS, 4, 4, 16, 8, false, 2>(p, stream);
           case 138: return launch_m1<BITS, 2, 3, 16, 16, false, 4>(p, stream);   // 16 waves x 2 k-blocks
           case 139: return launch_m1<BITS, 2, 3, 16, 16, false, 7>(p, stream);   // ... all 8 loads of a wave up front
           case 140: return launch_m1<BITS, 2, 3, 16, 16, false, 2>(p, stream);
-          case 141: return launch_la<BITS, 2, 3, 16, 16, 2, 7>(p, stream);       // ... loads only
-          case 142: return launch_la<BITS, 2, 3, 16, 16, 2, 4>(p, stream);
           default: break;
         }
       }
@@ -1251,11 +1042,14 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       // most of the chip (>= 192 whole-K tiles, or the 16-column tiles of few-column layers from 3 bits up), and the
       // wide-word widths everywhere (5/6/7-bit: 4096x14336 17.8 -> 9.0 us at 5 bits).  Not 2-bit with few columns
       // (4096x4096: 4.1 against 4.5 us), not the 128-column-tile shapes of 4/8-bit below, not 160-tile layers at 2-4 and
-      // 8 bits (5120x5120 w4: 6.4 against 7.4: ten waves per workgroup there against this kernel's eight).
+      // 8 bits (5120x5120 w4: 6.4 against 7.4: ten waves per workgroup there against this kernel's eight).  Two to four
+      // rows (the 4-row build): 4- and 8-bit only, a few per cent (4096x11008 M=4: w4 7.75 -> 7.52, w8 11.7 -> 10.9; 3-bit
+      // loses 0.2-1.5 us to its longer unpack beside four rows of activations; profiles/r03/sweep_rows_2_to_4.txt).
       const bool small_n = cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128;
       const bool wide = (BITS == 4 || BITS == 8) && p.n >= 25600u && kblocks / UBMAX >= 32;
       const uint32_t dyn_tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
-      const bool wins = small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
+      const bool wins = p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 192u)
+                                 : small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
       if ((wins && !wide) || (XBIT_TUNING && variant >= 300)) {
         const int st = try_dyn(cpl, small_n);
         if (st != kGemvDynNotEligible) return st;
