@@ -74,7 +74,6 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-launches", type=int, default=MIN_ROOFLINE_LAUNCHES, help="event-bracketed cold launches (at least 200)")
     ap.add_argument("--warm", action="store_true", help="also report the cache-resident kernel time (one weight copy)")
     ap.add_argument("--variant", type=int, default=-1, help="tuning builds only: GEMV launch-shape variant")
-    ap.add_argument("--spinup", type=int, default=0, help="untimed steps queued between the blocker and the first timed step (measurement probe)")
     return ap.parse_args(argv)
 
 
@@ -332,11 +331,14 @@ def main(argv=None):
             dist.barrier()
 
     # ---- untimed: touch every weight copy once (a first touch pays GPU page-table walks: with W = 5 the
-    # timed steps would otherwise be the first to read most copies, +1.2 us per step), then W warm-up steps
+    # timed steps would otherwise be the first to read most copies, +1.2 us per step).  The W warm-up steps
+    # themselves are queued directly AHEAD of the timed steps (below), not here: a warm-up that ends in a host
+    # wait leaves the chip idle again, and the first timed steps then pay the memory system's wake-up
+    # (20 timed steps: 7.03-7.23 us per step against 7.00-7.08 with 5 warm-up steps in the chain and 6.84-6.90 with
+    # 100; profiles/r03/bench_k20_probe.txt).
     sp0 = torch.cuda.current_stream(dev).cuda_stream
     for c in range(copies):
         kernel_step(c, sp0)
-    run_steps(0, W)
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, HIP events on the compute stream, host clock beside them.
@@ -344,7 +346,7 @@ def main(argv=None):
     # enqueue time, so the event-to-event span holds device time only: K x (kernel + launch boundary).
     # (A hipGraph replay measures the same per step — tools/bench_timing_probe.py — once its first,
     # slower replay is out of the way; --graph times that instead.)
-    graph, graph_note = None, ""
+    graph, warm_graph, graph_note = None, None, ""
     if (args.graph and world == 1 and not collective) or (collective and backend == "nccl" and not args.no_graph):
         # One GPU: on request.  Sharded layer over RCCL: by default - K x (GEMV + all-gather) recorded ONCE into a hipGraph
         # and replayed, so that the timed region holds device time (kernel + collective) and not the host's ~5 us of
@@ -357,6 +359,13 @@ def main(argv=None):
             g.replay()  # the first replay of a graph pays a one-off ~40 us on the device: untimed
             torch.cuda.synchronize()
             graph = g
+            if W > 0:  # the W warm-up steps as a graph of their own, replayed directly ahead of the timed one
+                gw = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gw):
+                    run_steps(0, W)
+                gw.replay()
+                torch.cuda.synchronize()
+                warm_graph = gw
         except Exception as exc:  # noqa: BLE001 - any capture failure means "time it eagerly"
             graph_note = "graph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc).splitlines()[0][:160] if str(exc) else "")
             torch.cuda.synchronize()
@@ -364,7 +373,7 @@ def main(argv=None):
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank replays, or none does
         if int(ok.item()) == 0 and graph is not None:
-            graph, graph_note = None, "graph capture failed on another rank; eager launches"
+            graph, warm_graph, graph_note = None, None, "graph capture failed on another rank; eager launches"
 
     stream = torch.cuda.current_stream(dev)
     blocker_cycles = 0
@@ -375,15 +384,18 @@ def main(argv=None):
         c1.record(stream)
         torch.cuda.synchronize()
         cycles_per_us = 1000000 / (c0.elapsed_time(c1) * 1e3)
-        blocker_cycles = int((100 + (0 if graph is not None else 12 * (K + args.spinup))) * cycles_per_us)
+        blocker_cycles = int((100 + (0 if graph is not None else 12 * (K + W))) * cycles_per_us)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if blocker_cycles:
         torch.cuda._sleep(blocker_cycles)
-    if args.spinup and graph is None:
-        run_steps(W - args.spinup, args.spinup)  # untimed: the chip leaves the blocker's near-idle state before ev0
+    # the W untimed warm-up steps, back to back with the timed ones
+    if graph is None:
+        run_steps(0, W)
+    elif warm_graph is not None:
+        warm_graph.replay()
     ev0.record(stream)
     if graph is not None:
         graph.replay()

@@ -5,6 +5,7 @@ set -o pipefail
 OUT=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
+OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES \
   --output-format csv -d "$OUT/sq" -o bench -- python3 "$ROOT/bench.py" --no-cpu --steps 30 --warmup 5 --roofline-launches 200 "$@" > "$OUT/sq.log" 2>&1
