@@ -191,6 +191,30 @@ def _run_m(lib, p, bias, dev, variant=-1):
 
 
 @pytest.mark.parametrize("bits", range(2, 9))
+def test_five_to_sixteen_rows_production(bits, cuda_device):
+    """What the production rule sends to the 8- and 16-row builds: layers with many tiles at 5..16 rows, few-column layers
+    at 9..16 rows on 32-column tiles, a K whose scale table needs more than the two static staging rounds (8192: 64 groups);
+    11008x4096 (long K on few tiles) stays with the round-2 pass and is checked all the same."""
+    lib = _lib.load()
+    for k, n, g, m in [(4096, 6144, 128, 5), (4096, 6144, 128, 16), (8192, 4096, 128, 16), (11008, 4096, 128, 16), (8192, 6144, 128, 9), (2048, 11008, 64, 8)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 3 + m + k)
+        y = _run_rows(lib, p, 1, cuda_device)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, k, n, g, m))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+@pytest.mark.parametrize("variant", [302, 303, 304])
+def test_five_to_sixteen_rows_forced_tile_shapes(bits, variant, cuda_device):
+    """The 8- and 16-row builds (every wave fetches and permutes the activations of its own next unit): every tile width,
+    both staging-round counts, an edge tile, a K that ends inside a unit; each row equals the oracle."""
+    lib = _lib.load_tuning()
+    for k, n, g, m in [(4096, 1030, 128, 16), (2048, 2048, 64, 8), (8192, 344, 128, 5), (4104, 96, 128, 9), (1024, 64, 128, 12)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 5 + variant + m)
+        y = _run_m(lib, p, 1, cuda_device, variant)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, variant, k, n, g, m))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
 @pytest.mark.parametrize("variant", [302, 303, 304])
 def test_two_to_four_rows_forced_tile_shapes(bits, variant, cuda_device):
     """The 4-row build (rows 2..4 per launch): every tile width, two staging-round counts, an edge tile; each row equals the

@@ -125,8 +125,14 @@ struct DynParams {
 //          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
 //          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
 //          column more than the contiguous build, no change to the weight stream.
-//   MT     activation rows per launch (1 or 4): the MFMA's A operand carries row (lane & 15) % MT, the staged activation
-//          image holds MT rows per octet, D rows 0..MT-1 are the results (the rest are copies)
+//   MT     activation rows per launch (1, 4, 8 or 16): the MFMA's A operand carries row (lane & 15) % MT, the staged
+//          activation image holds MT rows per octet, D rows 0..MT-1 are the results (the rest are copies).  1 and 4: the
+//          staging waves put the whole K range of every row into LDS up front.  8 and 16 (2 / 4 KB of activations per unit -
+//          the whole K range would be 64 / 128 KB at K = 4096): every wave fetches the activations of ITS next unit itself,
+//          one unit ahead - the loads go out when a unit starts, in front of every row request that unit makes for the
+//          next one, and are permuted into the wave's own 2-4 KB of LDS when the next unit starts; by then they are the
+//          oldest loads in flight, so the wait costs nothing the unit's first rows would not have cost anyway.  No
+//          workgroup barrier besides the one behind the scale table.
 template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1>
 __global__ void __launch_bounds__(64 * NW)
     gemv_dyn_kernel(const uint32_t* qweight, uint32_t n, uint32_t tiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales,
@@ -148,7 +154,9 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(NL == 16 || NL == 8, "lanes along N");
   static_assert(STW >= 1 && STW <= NW, "staging waves");
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
-  static_assert(MT == 1 || MT == 4, "rows per launch");
+  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16, "rows per launch");
+  constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
+  static_assert(!WAVEACT || (NL == 16 && !SPLIT && !GIDX && FLAGS == 0), "8 / 16 rows: whole-K tiles of 16 lanes, contiguous groups");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
   //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * MT * CN floats][bad flags: 8 dwords]
@@ -182,7 +190,7 @@ __global__ void __launch_bounds__(64 * NW)
   // (a) activations: chunk c = k CHK*c .. CHK*c + CHK - 1; (b) per group and column: scale and zero-point of staging
   // thread e's (group e / NL, lane slot e % NL).  Rounds past the end fall off the end of their tensors (the descriptors
   // return zeros, no traffic); lane slots past the last column read some other column's values, which are never stored.
-  u32x4_t act_raw[SI][MT][CPT];
+  u32x4_t act_raw[WAVEACT ? 1 : SI][WAVEACT ? 1 : MT][CPT];
   uint32_t s_raw[SI][2], z_raw[SI][2];
   u32x4_t g_raw[GIDX ? SI : 1][2];  // act-order: the ids of 8 consecutive rows per round
   const rsrc_t r_g = make_rsrc(GIDX ? static_cast<const void*>(p.g_idx) : static_cast<const void*>(p.a), GIDX ? p.k * 4u : 0u);
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(64 * NW)
       }
     }
 #pragma unroll
-    for (int r = 0; r < SI; ++r) {
+    for (int r = 0; r < (WAVEACT ? 0 : SI); ++r) {
       const uint32_t c = (uint32_t)(r * ST + tid);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
@@ -267,6 +275,64 @@ __global__ void __launch_bounds__(64 * NW)
       else X[f - 2 * R].load(r_w, lane_off, unit_off(nn) + (uint32_t)(f - 2 * R) * row_bytes);
     });
   };
+  // ---- 8 / 16 rows: this wave's activations, one unit at a time (see MT) ----
+  constexpr int TPR = LK * UB * (32 / CHK);           // chunks per row and unit
+  constexpr int WTASKS = WAVEACT ? MT * TPR : 64;     // chunks per unit
+  constexpr int AR = WAVEACT ? WTASKS / 64 : 1;       // rounds: one chunk per lane and round
+  static_assert(WTASKS % 64 == 0, "a unit's chunks fill whole rounds");
+  u32x4_t wa_raw[AR][CPT];
+  // dwords per octet of the per-wave image: MT rows of 16 B plus one empty slot, so that the 16 lanes that store one row's
+  // 16 octets (272 B apart, not 256) and the 16 lanes that read one octet's 16 rows both touch 64 different banks
+  constexpr int OST = WAVEACT ? (MT + 1) * 4 : MT * 4;
+  uint32_t* const my_act = s_act + (uint32_t)wv * (uint32_t)(LK * UB * 4 * OST);
+  // chunk t = lane + 64 * round: row t / TPR, chunk t % TPR of the unit - a row's chunks sit in neighbouring lanes (coalesced)
+  auto wact_issue = [&](uint32_t u) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const uint32_t t = (uint32_t)(lane + 64 * r), mi = t / (uint32_t)TPR, cu = t % (uint32_t)TPR;
+      const uint32_t k0 = u * (uint32_t)(LK * UB * 32) + cu * (uint32_t)CHK;
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        // rows beyond m fall off the end of the tensor (zeros); k beyond the row would read on into the next row: forced out of
+        // range.  A unit beyond the wave's last one reads something real and is never stored.
+        const uint32_t kq = k0 + 8u * (uint32_t)q;
+        wa_raw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, (mi * p.k + kq) * 2u | (kq >= p.k ? kOob : 0u), 0, 0);
+      }
+    }
+  };
+  auto wact_store = [&]() {
+    __builtin_amdgcn_wave_barrier();  // the previous unit's reads of this region come first
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const uint32_t t = (uint32_t)(lane + 64 * r), mi = t / (uint32_t)TPR, cu = t % (uint32_t)TPR;
+      uint32_t h[CHK / 2];
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        h[4 * q + 0] = wa_raw[r][q].x;
+        h[4 * q + 1] = wa_raw[r][q].y;
+        h[4 * q + 2] = wa_raw[r][q].z;
+        h[4 * q + 3] = wa_raw[r][q].w;
+      }
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pr = 4 * q + e;
+          const int klo = Unpack<BITS>::pair_k(pr, 0), khi = Unpack<BITS>::pair_k(pr, 1);
+          const uint32_t sel = (uint32_t)(2 * (klo & 1)) | ((uint32_t)(2 * (klo & 1) + 1) << 8) | ((uint32_t)(4 + 2 * (khi & 1)) << 16) |
+                               ((uint32_t)(5 + 2 * (khi & 1)) << 24);
+          o[e] = __builtin_amdgcn_perm(h[khi >> 1], h[klo >> 1], sel);
+        }
+        *reinterpret_cast<u32x4_t*>(my_act + (cu * (uint32_t)CPT + (uint32_t)q) * (uint32_t)OST + mi * 4u) = o;
+      }
+    }
+    // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  if constexpr (WAVEACT) wact_issue(cur);  // ahead of the first rows: the oldest loads of this wave
   request(ra, rb, std::integral_constant<int, 0>{}, std::integral_constant<int, P::open>{});
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (STAMP) stamp[6] = __builtin_amdgcn_s_memrealtime();  // first rows requested
@@ -275,7 +341,7 @@ __global__ void __launch_bounds__(64 * NW)
   bool bad = false;
   if (stager) {
 #pragma unroll
-    for (int r = 0; r < SI; ++r) {
+    for (int r = 0; r < (WAVEACT ? 0 : SI); ++r) {
       const uint32_t c = (uint32_t)(r * ST + tid);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
@@ -355,9 +421,10 @@ __global__ void __launch_bounds__(64 * NW)
     };
 #pragma unroll
     for (int r = 0; r < SI; ++r) tab_store((uint32_t)(r * ST + tid), s_raw[r], z_raw[r]);
-    if constexpr (GIDX) {
+    if constexpr (GIDX || MT >= 8) {
       // more groups than SI rounds of table entries (small or odd group sizes: K = 4096 at group 16 has 256): the rest one
-      // round at a time, load -> store.  Only the by-id build pays for the loop; its table holds every group of the layer.
+      // round at a time, load -> store.  Only the by-id build (its table holds every group of the layer) and the 8- / 16-row
+      // builds (one build for every K: 2 static rounds cover K = 4096 at group 128) pay for the loop.
       for (uint32_t e = (uint32_t)(SI * ST + tid); e < p.tab_groups * (uint32_t)NL; e += (uint32_t)ST) {
         uint32_t sr[2], zr[2];
         tab_load(e, sr, zr);
@@ -395,7 +462,8 @@ __global__ void __launch_bounds__(64 * NW)
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   // dwords: this lane's k-blocks of the unit (4 octets each, MT rows of 4 dwords per octet), its row of the A operand
-  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(16 * MT) + (uint32_t)(nl % MT) * 4u;
+  constexpr int OSTEP = MT >= 8 ? (MT + 1) * 4 : MT * 4;  // dwords from one octet to the next (8 / 16 rows: padded, see OST)
+  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(4 * OSTEP) + (uint32_t)(nl % MT) * 4u;
 
   // per-unit dequant constants of this lane's columns
   auto unit_consts = [&](uint32_t u, half2_t(&s2)[CPL], half2_t(&nzs2)[CPL], half2_t(&ss2)[CPL]) {
@@ -416,7 +484,7 @@ __global__ void __launch_bounds__(64 * NW)
                   const half2_t(&ss2)[CPL], const uint32_t(&gq)[GIDX ? UB : 1][16]) {
     constexpr int s = decltype(s_c)::value, j = s / 4, oct = s % 4;
     constexpr bool FAST = decltype(fast_c)::value;
-    const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 16 + 4 * oct) * MT);
+    const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OSTEP);
     const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
     uint32_t wc[CPL][BITS];
 #pragma unroll
@@ -479,8 +547,13 @@ __global__ void __launch_bounds__(64 * NW)
   auto process = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R]) {
     const bool live = cur < uend;  // wave-uniform
     half2_t s2[CPL], nzs2[CPL], ss2[CPL];
-    const uint32_t* const a_unit = s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
+    const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
     uint32_t gq[GIDX ? UB : 1][16];
+    if constexpr (WAVEACT) {
+      if (live) wact_store();  // this unit's activations: requested one unit ago, the oldest loads in flight
+      wact_issue(nxt);         // the next unit's: in front of every row this unit will request for it
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (live) {
       if constexpr (GIDX) unit_ids(cur, gq);
       else unit_consts(cur, s2, nzs2, ss2);
@@ -517,7 +590,11 @@ __global__ void __launch_bounds__(64 * NW)
       Row<CPL, NT> rs[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) rs[i].load(r_w, lane_off, u * unit_bytes + (uint32_t)i * row_bytes);
-      const uint32_t* const a_unit = s_act + (u - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
+      if constexpr (WAVEACT) {
+        wact_issue(u);
+        wact_store();
+      }
+      const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : s_act + (u - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
       static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2, gq); });
     }
   }
@@ -532,17 +609,26 @@ __global__ void __launch_bounds__(64 * NW)
   {
     const int h = NL == 16 ? 0 : (lane >= 32 ? 1 : 0);
     const bool holder = NL == 16 ? lane < 16 : (lane < 8 || (lane >= 40 && lane < 48));
-    if (holder) {
+    if constexpr (WAVEACT) {  // rows 4 * (lane >> 4) + r, all four lane groups up to MT
+      if (4 * (lane >> 4) < MT) {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c)
+        for (int c = 0; c < CPL; ++c)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) s_red[((wv * HS + h) * MT + mi) * CN + (lane % NL) * CPL + c] = acc[c][mi];
+          for (int r = 0; r < 4; ++r) s_red[(wv * MT + 4 * (lane >> 4) + r) * CN + nl * CPL + c] = acc[c][r];
+      }
+    } else {
+      if (holder) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) s_red[((wv * HS + h) * MT + mi) * CN + (lane % NL) * CPL + c] = acc[c][mi];
+      }
     }
   }
   __syncthreads();
   if constexpr (STAMP) stamp[4] = __builtin_amdgcn_s_memrealtime();
-  if (tid < MT * CN) {
-    const int mi = tid / CN, cc = tid % CN;
+  for (int e0 = tid; e0 < MT * CN; e0 += 64 * NW) {
+    const int mi = e0 / CN, cc = e0 % CN;
     float sum = 0.f;
 #pragma unroll
     for (int w = 0; w < NW * HS; ++w) sum += s_red[(w * MT + mi) * CN + cc];
@@ -555,7 +641,7 @@ __global__ void __launch_bounds__(64 * NW)
       // or NaN); integer addition is associative, so the result does not depend on the arrival order.  The thread that
       // completes the count converts, stores and clears the slot.  Contract: include/xbitops_hip.h (split_k).
       if (valid) {
-        unsigned long long* slot = p.acc + (size_t)tile * (size_t)(MT * CN) + (size_t)tid;
+        unsigned long long* slot = p.acc + (size_t)tile * (size_t)(MT * CN) + (size_t)e0;
         const bool fin = __builtin_fabsf(sum) < 524288.0f;
         const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;
         const unsigned long long pos = (!fin && !(sum < 0.f)) ? (1ull << 56) : 0ull;
@@ -641,6 +727,14 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
     }
     return kDynNotEligible;
   }
+  if (p.m > 4u) {  // 5..16 rows: the per-wave activation pipeline (8- and 16-row builds); the rounds stage the table only
+    if constexpr (NL == 16) {
+      if (p.splits > 1u) return kDynNotEligible;
+      if (p.m <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
+      return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
+    }
+    return kDynNotEligible;
+  }
   if (p.m > 1u) {  // 2..4 rows: whole-K tiles of 16 lanes, K up to 4096 (2 rounds) or 8192 (4 rounds)
     if constexpr (NL == 16) {
       if (p.splits > 1u) return kDynNotEligible;
@@ -674,7 +768,8 @@ template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g.m < 1u || g.m > 4u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
+  if (g.m < 1u || g.m > 16u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
+  if (g.m > 4u && (g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || nl != 16)) return kDynNotEligible;  // 5..16 rows: contiguous groups, whole K
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
   // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column
   // tiles, whole K, every group in the LDS table.
@@ -717,8 +812,9 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   p.ups = (p.units + p.splits - 1u) / p.splits;
   p.acc = acc;
   if (p.splits > 1u && (p.ups < 8u || (p.splits - 1u) * p.ups >= p.units)) return kDynNotEligible;  // every range holds a unit for every wave
-  const uint32_t mt = g.m > 1u ? 4u : 1u;
+  const uint32_t mt = g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u));
   p.act_bytes = p.ups * lk * UB * 64u * mt;
+  if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
   // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
   // launches cover at least `groups` rows so that the zero rows past the last group exist
   p.tab_groups = ((p.ups * lk - 1u + ((1u << p.gshift) - 1u)) >> p.gshift) + 1u;
@@ -731,7 +827,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
   if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
   constexpr uint32_t st = 64u * kDynStagers;
-  const uint32_t chunks = p.act_bytes / mt / (uint32_t)(Unpack<BITS>::kChunkK * 2);  // a staging thread takes one chunk of every row per round
+  const uint32_t chunks = mt >= 8u ? 0u : p.act_bytes / mt / (uint32_t)(Unpack<BITS>::kChunkK * 2);  // a staging thread takes one chunk of every row per round
   const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
   const uint32_t r_gid = by_id ? (p.act_bytes / mt / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round
   const uint32_t r_tab_static = by_id ? 0u : r_tab;  // the by-id build stages table entries beyond its static rounds in a loop

@@ -894,9 +894,12 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
   // 64 columns, 310-314 the same with plain instead of nontemporal row loads, 320 stamped (tools/gemv_trace_detail.py),
   // 399 never (the whole-K kernels of this file, unsplit, for A/B), 398 never, but with this file's own launch rules (split-K
   // included): the round-2 library.
+  bool rows16_rule = false;  // set by the launch rule below when 5..16 rows go to the staged-operand kernel
   auto try_dyn = [&](int auto_cpl, bool auto_small_n) -> int {
-    if (p.m > 4u) return kGemvDynNotEligible;
-    if (p.m > 1u && (auto_small_n || !(BITS == 4 || BITS == 8)) && !(XBIT_TUNING && variant >= 300))
+    if (p.m > 16u) return kGemvDynNotEligible;
+    if (p.m > 4u && !(XBIT_TUNING && variant >= 300) && !rows16_rule) return kGemvDynNotEligible;
+    if (p.m > 4u && auto_small_n && !(XBIT_TUNING && variant >= 302 && variant <= 304)) return kGemvDynNotEligible;  // 16-column tiles take one row
+    if (p.m > 1u && p.m <= 4u && (auto_small_n || !(BITS == 4 || BITS == 8)) && !(XBIT_TUNING && variant >= 300))
       return kGemvDynNotEligible;  // the 16-column tiles take one row; 2-4 rows pay at 4 and 8 bits only (rule below)
     int dcpl = auto_small_n ? 2 : auto_cpl, dnl = auto_small_n ? 8 : 16;
     bool nt = true, stamped = false;
@@ -1048,10 +1051,20 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       const bool small_n = cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128;
       const bool wide = (BITS == 4 || BITS == 8) && p.n >= 25600u && kblocks / UBMAX >= 32;
       const uint32_t dyn_tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
-      const bool wins = p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 192u)
-                                 : small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
-      if ((wins && !wide) || (XBIT_TUNING && variant >= 300)) {
-        const int st = try_dyn(cpl, small_n);
+      // Five to sixteen rows (the 8- and 16-row builds: every wave fetches its own next unit's activations): wherever the
+      // tiles are 32 columns and more, every width - 4096x11008 w4 8.3 -> 7.6 us at 8 rows and 9.2 -> 8.6 at 16, 5120x13824
+      // 13.5 -> 10.0 and 15.3 -> 11.6, 8192x8192 11.3 -> 9.8 and 13.4 -> 11.8 (profiles/r03/sweep_rows_8_16*.txt); not
+      // where 128-column tiles serve up to 8 rows (8192x28672 w4: 25.4 against 27.8).
+      // Few-column layers: up to 8 rows stay on the 16-column tiles of this file; 9..16 rows take 32-column tiles there
+      // (4096x4096 w4 7.3 -> 6.5 us, 8192x3584 12.2 -> 11.0).
+      // Not long K on few tiles (13824x5120, 160 tiles: 17.3 -> 19.2 us at 8 rows - this file's passes run up to 14 waves
+      // per workgroup there; sweep_rows_5_16_rule_check_before_long_k_exclusion.txt).
+      rows16_rule = p.m > 4u && p.m <= 16u && !(small_n && p.m <= 8u) && !(wide && p.m <= 8u) && (dyn_tiles >= 192u || kblocks <= 256u);
+      const bool wins = p.m > 4u ? rows16_rule
+                        : p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 192u)
+                                   : small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
+      if ((wins && (!wide || p.m > 8u)) || (XBIT_TUNING && variant >= 300)) {
+        const int st = try_dyn(cpl, small_n && p.m <= 8u);
         if (st != kGemvDynNotEligible) return st;
       }
     }
