@@ -20,10 +20,14 @@ every timed launch streams from HBM ("cold").
 Printed JSON (one line, rank 0)
   value / ms_per_step  algorithmic bytes of all ranks x K / the time of exactly K steps, measured with
                        HIP events recorded ON THE COMPUTE STREAM around the region,
-                       max over ranks, between barrier + synchronize pairs.  On one GPU the K
-                       launches are queued behind a blocker kernel that outlasts the host's enqueue time,
-                       so the span holds device time only: K x (kernel + launch boundary,
-                       `boundary_us_per_step`); `host_clock_ms_per_step` is the host's view (blocker included).
+                       max over ranks, between barrier + synchronize pairs.  On one GPU the W warm-up
+                       launches and the K timed ones are queued, in that order, behind a blocker kernel that
+                       outlasts the host's enqueue time, so the span holds device time only: K x (kernel +
+                       launch boundary, `boundary_us_per_step`), and the timed steps start on a chip that is
+                       already streaming; `host_clock_ms_per_step` is the host's view (blocker included).
+                       N > 1 on RCCL: the K x (GEMV + all-gather) steps are one captured hipGraph (the W warm-up
+                       steps another, replayed directly ahead); `collective_us_per_step` = step - kernel;
+                       `graph_note` says so when the capture failed and the region ran eagerly.
   roofline             algorithmic bytes per launch / mean KERNEL duration over >= 200 cold launches
                        (whatever --steps says), each bracketed by its own pair of HIP events on its own stream
                        (hipExtLaunchKernel via xbit_profile_series_begin/_end) and queued back to back like the

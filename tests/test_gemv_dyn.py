@@ -215,6 +215,29 @@ def test_five_to_sixteen_rows_forced_tile_shapes(bits, variant, cuda_device):
 
 
 @pytest.mark.parametrize("bits", range(2, 9))
+def test_seventeen_to_sixty_four_rows_production(bits, cuda_device):
+    """17..32 rows: one launch of the 32-row build on layers with many tiles; 33..64: two such launches; a few-column layer
+    (two 16-row passes of the round-2 kernel) beside them."""
+    lib = _lib.load()
+    for k, n, g, m in [(4096, 6144, 128, 17), (4096, 6144, 128, 32), (4096, 6144, 128, 33), (2048, 11008, 64, 64), (4096, 1024, 128, 40)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 3 + m + k)
+        y = _run_rows(lib, p, 1, cuda_device)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, k, n, g, m))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+@pytest.mark.parametrize("variant", [302, 303, 304])
+def test_seventeen_to_thirty_two_rows_forced_tile_shapes(bits, variant, cuda_device):
+    """The 32-row build (two A operands - rows 0-15 and 16-31 - per unpacked B fragment): every tile width, an edge tile, a K
+    that ends inside a unit; each row equals the oracle."""
+    lib = _lib.load_tuning()
+    for k, n, g, m in [(4096, 1030, 128, 32), (2048, 2048, 64, 17), (8192, 344, 128, 24), (4104, 96, 128, 31)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 5 + variant + m)
+        y = _run_m(lib, p, 1, cuda_device, variant)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, variant, k, n, g, m))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
 @pytest.mark.parametrize("variant", [302, 303, 304])
 def test_two_to_four_rows_forced_tile_shapes(bits, variant, cuda_device):
     """The 4-row build (rows 2..4 per launch): every tile width, two staging-round counts, an edge tile; each row equals the

@@ -49,16 +49,16 @@ def test_quant_linear_forward(bits, bias, cuda_device):
     w_deq = layer.dequantize()
     assert np.array_equal(w_deq.cpu().numpy().view(np.uint16), w_ref.view(np.uint16))  # bit-exact vs the oracle
     assert (w_deq.float().cpu() - w).abs().max() < (0.05 if bits >= 4 else 0.12)
-    for rows in (1, 5, 16):  # GEMV path (1, 8- and 16-row passes): the oracle GEMV on the same packed buffers
+    for rows in (1, 5, 16, 40, 128):  # fused path (up to GEMV_MAX_ROWS rows): the oracle GEMV on the same packed buffers
         x = (torch.randn(rows, 512, device=cuda_device) * 0.5).half()
         y = layer(x)
         assert y.shape == (rows, 128)
         _assert_close_to_oracle(y, _oracle_forward(layer, x), "bits=%d rows=%d" % (bits, rows))
-    # dequant + dense GEMM path (> 16 rows): fp16 GEMM of the oracle's W, fp32 accumulation order unknown
-    x = (torch.randn(40, 512, device=cuda_device) * 0.5).half()
+    # dequant + dense GEMM path (more rows): fp16 GEMM of the oracle's W, fp32 accumulation order unknown
+    x = (torch.randn(200, 512, device=cuda_device) * 0.5).half()
     y = layer(x)
     y_ref = oracle.matvec_f16(x.cpu().numpy(), w_ref).astype(np.float64)
-    assert y.shape == (40, 128)
+    assert y.shape == (200, 128)
     assert (np.abs(y.float().cpu().numpy() - y_ref) <= 2e-3 * np.abs(y_ref) + 1e-3).all()
     assert layer(torch.zeros(2, 3, 512, device=cuda_device).half()).shape == (2, 3, 128)
 

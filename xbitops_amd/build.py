@@ -18,6 +18,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -73,11 +74,15 @@ def _compile(src: str, keep_asm: bool, tuning: bool, force: bool = False) -> str
     cmd = [hipcc()] + CXXFLAGS + (["-DXBIT_TUNING=1"] if tuning else []) + ["-MD", "-MF", obj + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
     if keep_asm:
         cmd += ["-save-temps=obj"]
+    started = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=objdir)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    # the object carries the time its compile STARTED: a header edited while the compiler ran (these translation units
+    # take minutes) then still counts as newer than the object, and the next build recompiles it
+    os.utime(obj, (started, started))
     return obj
 
 

@@ -125,7 +125,8 @@ struct DynParams {
 //          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
 //          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
 //          column more than the contiguous build, no change to the weight stream.
-//   MT     activation rows per launch (1, 4, 8 or 16): the MFMA's A operand carries row (lane & 15) % MT, the staged
+//   MT     activation rows per launch (1, 4, 8, 16 or 32; 32: two A operands - rows 0-15 and 16-31 - per unpacked B fragment,
+//          so every weight is unpacked once for all 32 rows): the MFMA's A operand carries row (lane & 15) % MT, the staged
 //          activation image holds MT rows per octet, D rows 0..MT-1 are the results (the rest are copies).  1 and 4: the
 //          staging waves put the whole K range of every row into LDS up front.  8 and 16 (2 / 4 KB of activations per unit -
 //          the whole K range would be 64 / 128 KB at K = 4096): every wave fetches the activations of ITS next unit itself,
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(NL == 16 || NL == 8, "lanes along N");
   static_assert(STW >= 1 && STW <= NW, "staging waves");
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
-  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16, "rows per launch");
+  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
   static_assert(!WAVEACT || (NL == 16 && !SPLIT && !GIDX && FLAGS == 0), "8 / 16 rows: whole-K tiles of 16 lanes, contiguous groups");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -456,14 +457,16 @@ __global__ void __launch_bounds__(64 * NW)
   const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(s_bad), b1 = *reinterpret_cast<const u32x4_t*>(s_bad + 4);
   const bool fast = __builtin_amdgcn_readfirstlane((int)(b0.x | b0.y | b0.z | b0.w | b1.x | b1.y | b1.z | b1.w)) == 0;
 
-  f4_t acc[CPL];
+  f4_t acc[CPL], acc_hi[MT == 32 ? CPL : 1];  // acc_hi: rows 16-31 of the 32-row build
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < (MT == 32 ? CPL : 1); ++c) acc_hi[c] = f4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   // dwords: this lane's k-blocks of the unit (4 octets each, MT rows of 4 dwords per octet), its row of the A operand
   constexpr int OSTEP = MT >= 8 ? (MT + 1) * 4 : MT * 4;  // dwords from one octet to the next (8 / 16 rows: padded, see OST)
-  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(4 * OSTEP) + (uint32_t)(nl % MT) * 4u;
+  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(4 * OSTEP) + (uint32_t)(nl % (MT > 16 ? 16 : MT)) * 4u;
 
   // per-unit dequant constants of this lane's columns
   auto unit_consts = [&](uint32_t u, half2_t(&s2)[CPL], half2_t(&nzs2)[CPL], half2_t(&ss2)[CPL]) {
@@ -527,6 +530,13 @@ __global__ void __launch_bounds__(64 * NW)
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
       acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+    if constexpr (MT == 32) {  // rows 16-31: the same B fragments once more
+      const u32x4_t araw_hi = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OSTEP + 64);
+      const h8_t a_hi = __builtin_bit_cast(h8_t, araw_hi);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        acc_hi[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, __builtin_bit_cast(h8_t, braw[c]), acc_hi[c], 0, 0, 0);
+    }
   };
   // act-order: the ids of the lane's k-blocks of unit u (64 bytes per k-block)
   auto unit_ids = [&](uint32_t u, uint32_t(&gq)[GIDX ? UB : 1][16]) {
@@ -615,6 +625,12 @@ __global__ void __launch_bounds__(64 * NW)
         for (int c = 0; c < CPL; ++c)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s_red[(wv * MT + 4 * (lane >> 4) + r) * CN + nl * CPL + c] = acc[c][r];
+        if constexpr (MT == 32) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[(wv * MT + 16 + 4 * (lane >> 4) + r) * CN + nl * CPL + c] = acc_hi[c][r];
+        }
       }
     } else {
       if (holder) {
@@ -731,7 +747,8 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
     if constexpr (NL == 16) {
       if (p.splits > 1u) return kDynNotEligible;
       if (p.m <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
-      return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
+      if (p.m <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
+      return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
     }
     return kDynNotEligible;
   }
@@ -768,7 +785,7 @@ template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g.m < 1u || g.m > 16u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
+  if (g.m < 1u || g.m > 32u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
   if (g.m > 4u && (g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || nl != 16)) return kDynNotEligible;  // 5..16 rows: contiguous groups, whole K
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
   // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column
@@ -812,7 +829,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   p.ups = (p.units + p.splits - 1u) / p.splits;
   p.acc = acc;
   if (p.splits > 1u && (p.ups < 8u || (p.splits - 1u) * p.ups >= p.units)) return kDynNotEligible;  // every range holds a unit for every wave
-  const uint32_t mt = g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u));
+  const uint32_t mt = g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u)));
   p.act_bytes = p.ups * lk * UB * 64u * mt;
   if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
   // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
@@ -823,7 +840,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
     if (p.tab_groups < p.groups) p.tab_groups = p.groups;
   }
   if (by_id) p.tab_groups = p.groups;  // every group, whatever K
-  if (dyn_lds_bytes(p, nl, kDynWaves, cpl, (int)mt) > (by_id ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
+  if (dyn_lds_bytes(p, nl, kDynWaves, cpl, (int)mt) > (by_id || mt == 32u ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
   if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
   constexpr uint32_t st = 64u * kDynStagers;

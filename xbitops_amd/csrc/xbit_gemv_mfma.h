@@ -894,10 +894,11 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
   // 64 columns, 310-314 the same with plain instead of nontemporal row loads, 320 stamped (tools/gemv_trace_detail.py),
   // 399 never (the whole-K kernels of this file, unsplit, for A/B), 398 never, but with this file's own launch rules (split-K
   // included): the round-2 library.
-  bool rows16_rule = false;  // set by the launch rule below when 5..16 rows go to the staged-operand kernel
+  bool rows16_rule = false, rows32_rule = false;  // set by the launch rule below when 5..16 / 17..32 rows go to the staged-operand kernel
   auto try_dyn = [&](int auto_cpl, bool auto_small_n) -> int {
-    if (p.m > 16u) return kGemvDynNotEligible;
-    if (p.m > 4u && !(XBIT_TUNING && variant >= 300) && !rows16_rule) return kGemvDynNotEligible;
+    if (p.m > 32u) return kGemvDynNotEligible;
+    if (p.m > 16u && !(XBIT_TUNING && variant >= 300) && !rows32_rule) return kGemvDynNotEligible;
+    if (p.m > 4u && p.m <= 16u && !(XBIT_TUNING && variant >= 300) && !rows16_rule) return kGemvDynNotEligible;
     if (p.m > 4u && auto_small_n && !(XBIT_TUNING && variant >= 302 && variant <= 304)) return kGemvDynNotEligible;  // 16-column tiles take one row
     if (p.m > 1u && p.m <= 4u && (auto_small_n || !(BITS == 4 || BITS == 8)) && !(XBIT_TUNING && variant >= 300))
       return kGemvDynNotEligible;  // the 16-column tiles take one row; 2-4 rows pay at 4 and 8 bits only (rule below)
@@ -1060,7 +1061,26 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       // Not long K on few tiles (13824x5120, 160 tiles: 17.3 -> 19.2 us at 8 rows - this file's passes run up to 14 waves
       // per workgroup there; sweep_rows_5_16_rule_check_before_long_k_exclusion.txt).
       rows16_rule = p.m > 4u && p.m <= 16u && !(small_n && p.m <= 8u) && !(wide && p.m <= 8u) && (dyn_tiles >= 192u || kblocks <= 256u);
-      const bool wins = p.m > 4u ? rows16_rule
+      // Seventeen to thirty-two rows (the 32-row build: two A operands per unpacked B fragment, against two 16-row passes
+      // that unpack every weight twice): 4096x11008 w4 15.2 -> 11.5 us at 32 rows, 5120x13824 26.8 -> 16.3, 8192x8192 22.7 ->
+      // 16.8, 8192x28672 62 -> 43; not on few tiles (4096x4096 7.4 -> 8.6, 11008x4096 16.3 -> 21.1;
+      // profiles/r03/sweep_rows_17_32.txt).  33..128 rows: launches of 32 rows (each streams the weights once more), still
+      // ahead of 16-row passes (4096x11008 w4 at 64 rows: 22.1 us; dequantise + dense GEMM: 48.8, linear_crossover.txt).
+      rows32_rule = p.m > 16u && p.m <= 128u && dyn_tiles >= 192u;
+      if (p.m > 32u && (rows32_rule || (XBIT_TUNING && variant >= 300 && p.m <= 128u))) {
+        GemvParams q = p;
+        int st = XBIT_OK;
+        for (uint32_t r0 = 0; r0 < p.m && st == XBIT_OK; r0 += 32u) {
+          q.m = p.m - r0 < 32u ? p.m - r0 : 32u;
+          q.a = p.a + (size_t)r0 * p.k;
+          q.out = p.out + (size_t)r0 * p.n;
+          st = launch_gemv_dyn(q, BITS, stream, cpl, 16, true, false, nullptr);
+          if (st == kGemvDynNotEligible) break;  // the first chunk decides: nothing has been launched yet
+        }
+        if (st != kGemvDynNotEligible) return st;
+      }
+      const bool wins = p.m > 16u ? (rows32_rule && p.m <= 32u)
+                        : p.m > 4u ? rows16_rule
                         : p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 192u)
                                    : small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
       if ((wins && (!wide || p.m > 8u)) || (XBIT_TUNING && variant >= 300)) {

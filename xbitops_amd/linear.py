@@ -12,10 +12,13 @@ import torch
 
 from . import ops, packing
 
-# Rows served by the fused kernel.  One pass takes up to 16 rows; 17..32 rows are two passes over the packed weights
-# (4096x11008 w4: 14.6-15.2 us, profiles/r02/sweep_rows_per_call.txt), which still beats dequantising the layer first
-# (19.2 us for the dequant alone, before the dense GEMM); beyond that dequant + GEMM takes over.
-GEMV_MAX_ROWS = 32
+# Rows served by the fused kernel.  Up to 32 rows are one launch that unpacks every weight once; beyond that the library
+# launches 32 rows at a time (or 16-row passes on few-column layers), and the weights are streamed once per launch.  Measured
+# against dequantise + torch's dense fp16 GEMM, cold weights (profiles/r03/linear_crossover.txt, us per call): 4096x11008 w4
+# 11.1 against 45.1 at 32 rows, 22.1 / 48.8 at 64, 54.6 / 60.5 at 128; 4096x4096 22.5 / 43.4 at 128; 8192x8192 84 / 107 at
+# 128.  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM), so the fused one keeps
+# the lead up to about 128 rows.
+GEMV_MAX_ROWS = 128
 
 
 class QuantLinear(torch.nn.Module):
