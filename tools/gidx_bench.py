@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--bits", default="4")
     ap.add_argument("--rows", default="1")
     ap.add_argument("--group", type=int, default=128)
+    ap.add_argument("--dequant", action="store_true", help="time xbit_dequant_gidx_f16 against xbit_dequant_f16 instead")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _lib.load()
@@ -35,6 +36,26 @@ def main():
     equal = np.repeat(np.arange(groups), g)[:k].astype(np.int32)
     rng.shuffle(equal)
     unequal = rng.integers(0, groups, size=k).astype(np.int32)
+    if args.dequant:
+        print("# %dx%d group %d: dequant, us per launch, period of a dependent chain" % (k, n, g))
+        for bits in (int(b) for b in args.bits.split(",")):
+            base = synth.make_problem(k, n, bits, g, m=1, seed=bits)
+            qw, sc, qz = (torch.from_numpy(x).to(dev) for x in (base.qweight, base.scales, base.qzeros))
+            out = torch.empty((k, n), dtype=torch.float16, device=dev)
+            gd = torch.from_numpy(unequal).to(dev)
+
+            def plain(i):
+                assert lib.xbit_dequant_f16(out.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), bits, g, k, n, 1, sp) == 0
+
+            def by_id(i):
+                assert lib.xbit_dequant_gidx_f16(out.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gd.data_ptr(), bits, groups, k, n, 1, sp) == 0
+
+            for f in (plain, by_id):
+                for i in range(5):
+                    f(i)
+            torch.cuda.synchronize()
+            print("w%d  contiguous groups %7.2f us   g_idx %7.2f us" % (bits, gemv_sweep.chain_period(plain, 50, 0), gemv_sweep.chain_period(by_id, 50, 0)), flush=True)
+        return
     print("# %dx%d group %d: us per launch, period of a dependent chain, cold" % (k, n, g))
     for bits in (int(b) for b in args.bits.split(",")):
         for m in (int(r) for r in args.rows.split(",")):

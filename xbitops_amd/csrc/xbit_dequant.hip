@@ -30,8 +30,12 @@ constexpr int kDqThreads = kDqLanesN * kDqLanesK;
 // VAR (measurement builds, XBIT_DEQUANT_VARIANT): 0 = production; 1 = plain (not nontemporal) stores;
 // 2 = the 4 waves of a workgroup side by side along N (one k-block, 2048 columns: 4 KB per output row);
 // 3 = nontemporal packed-weight loads (the round-1 kernel); 5 / 6 / 7 = 8 / 2 / 1 waves per workgroup
-template <int BITS, bool GROUP_PER_BLOCK, int VAR = 0, int WAVES = kDqLanesK>
-__global__ void __launch_bounds__(kDqLanesN * WAVES) dequant_tile_kernel(const DequantParams p) {
+// BY_ID (act-order, xbit_dequant_gidx_f16): the group of row k is g_idx[k] (clamped to [0, groups)); a lane re-reads its 8
+// scales and zero-points whenever the group changes from one row to the next - every row for a shuffled g_idx, which makes
+// the op read about as many bytes from L2 as it writes (4096x11008 w4: 17.7 us contiguous, profiles/r03/gidx_dequant.txt).
+template <int BITS, bool GROUP_PER_BLOCK, int VAR = 0, int WAVES = kDqLanesK, bool BY_ID = false>
+__global__ void __launch_bounds__(kDqLanesN * WAVES) dequant_tile_kernel(const DequantParams p, const int32_t* g_idx) {
+  static_assert(!BY_ID || !GROUP_PER_BLOCK, "act-order: the group may change at every row");
   const int nl = threadIdx.x % kDqLanesN, kl = threadIdx.x / kDqLanesN;
   const uint32_t col = VAR == 2 ? ((blockIdx.x * WAVES + kl) * kDqLanesN + nl) * 8u : (blockIdx.x * kDqLanesN + nl) * 8u;
   const uint32_t kb = VAR == 2 ? blockIdx.y : blockIdx.y * WAVES + kl;
@@ -72,7 +76,15 @@ __global__ void __launch_bounds__(kDqLanesN * WAVES) dequant_tile_kernel(const D
     }
   };
 
-  uint32_t cur_g = k0 / p.groupsize;
+  auto group_of = [&](uint32_t k) -> uint32_t {
+    if constexpr (BY_ID) {
+      const uint32_t g = k < p.k ? (uint32_t)g_idx[k] : 0u;
+      return g < p.groups ? g : p.groups - 1u;  // out-of-range (or negative) ids are clamped, never followed
+    } else {
+      return k / p.groupsize;
+    }
+  };
+  uint32_t cur_g = group_of(k0);
   load_group(cur_g);
 
   uint32_t wcol[8][BITS];
@@ -87,7 +99,7 @@ __global__ void __launch_bounds__(kDqLanesN * WAVES) dequant_tile_kernel(const D
   for (int kk = 0; kk < 32; ++kk) {
     const bool row_ok = k0 + kk < p.k;  // ragged K: only rows < in_features exist (:77-84, :316-329)
     if constexpr (!GROUP_PER_BLOCK) {
-      const uint32_t g = (k0 + kk) / p.groupsize;
+      const uint32_t g = group_of(k0 + kk);
       if (row_ok && g != cur_g) {
         cur_g = g;
         load_group(g);
@@ -124,25 +136,40 @@ int launch_bits(const DequantParams& p, hipStream_t stream) {
   dim3 grid((p.n / 8 + kDqLanesN - 1) / kDqLanesN, (p.kblocks + kDqLanesK - 1) / kDqLanesK), block(kDqThreads);
 #if XBIT_TUNING
   static const int var = getenv("XBIT_DEQUANT_VARIANT") ? atoi(getenv("XBIT_DEQUANT_VARIANT")) : 0;
-  if (p.groupsize % 32u == 0 && var == 1) return launch(dequant_tile_kernel<BITS, true, 1>, grid, block, stream, p);
-  if (p.groupsize % 32u == 0 && var == 3) return launch(dequant_tile_kernel<BITS, true, 3>, grid, block, stream, p);
+  if (p.groupsize % 32u == 0 && var == 1) return launch(dequant_tile_kernel<BITS, true, 1>, grid, block, stream, p, static_cast<const int32_t*>(nullptr));
+  if (p.groupsize % 32u == 0 && var == 3) return launch(dequant_tile_kernel<BITS, true, 3>, grid, block, stream, p, static_cast<const int32_t*>(nullptr));
   if (p.groupsize % 32u == 0 && (var == 5 || var == 6 || var == 7)) {  // 8 / 2 / 1 waves (k-blocks) per workgroup
     const uint32_t wv = var == 5 ? 8u : var == 6 ? 2u : 1u;
     dim3 gridw((p.n / 8 + kDqLanesN - 1) / kDqLanesN, (p.kblocks + wv - 1) / wv), blockw(kDqLanesN * wv);
-    if (var == 5) return launch(dequant_tile_kernel<BITS, true, 0, 8>, gridw, blockw, stream, p);
-    if (var == 6) return launch(dequant_tile_kernel<BITS, true, 0, 2>, gridw, blockw, stream, p);
-    return launch(dequant_tile_kernel<BITS, true, 0, 1>, gridw, blockw, stream, p);
+    if (var == 5) return launch(dequant_tile_kernel<BITS, true, 0, 8>, gridw, blockw, stream, p, static_cast<const int32_t*>(nullptr));
+    if (var == 6) return launch(dequant_tile_kernel<BITS, true, 0, 2>, gridw, blockw, stream, p, static_cast<const int32_t*>(nullptr));
+    return launch(dequant_tile_kernel<BITS, true, 0, 1>, gridw, blockw, stream, p, static_cast<const int32_t*>(nullptr));
   }
   if (p.groupsize % 32u == 0 && var == 2) {
     dim3 grid2((p.n / 8 + kDqLanesN * kDqLanesK - 1) / (kDqLanesN * kDqLanesK), p.kblocks);
-    return launch(dequant_tile_kernel<BITS, true, 2>, grid2, block, stream, p);
+    return launch(dequant_tile_kernel<BITS, true, 2>, grid2, block, stream, p, static_cast<const int32_t*>(nullptr));
   }
 #endif
-  if (p.groupsize % 32u == 0) return launch(dequant_tile_kernel<BITS, true>, grid, block, stream, p);
-  return launch(dequant_tile_kernel<BITS, false>, grid, block, stream, p);
+  if (p.groupsize % 32u == 0) return launch(dequant_tile_kernel<BITS, true>, grid, block, stream, p, static_cast<const int32_t*>(nullptr));
+  return launch(dequant_tile_kernel<BITS, false>, grid, block, stream, p, static_cast<const int32_t*>(nullptr));
 }
 
 }  // namespace
+
+// act-order: the tile kernel with per-row group ids; the caller has checked the tile kernel's alignment rules
+int launch_dequant_by_id(const DequantParams& p, const int32_t* g_idx, int bits, hipStream_t stream) {
+  dim3 grid((p.n / 8 + kDqLanesN - 1) / kDqLanesN, (p.kblocks + kDqLanesK - 1) / kDqLanesK), block(kDqThreads);
+  switch (bits) {
+    case 2: return launch(dequant_tile_kernel<2, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    case 3: return launch(dequant_tile_kernel<3, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    case 4: return launch(dequant_tile_kernel<4, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    case 5: return launch(dequant_tile_kernel<5, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    case 6: return launch(dequant_tile_kernel<6, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    case 7: return launch(dequant_tile_kernel<7, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    case 8: return launch(dequant_tile_kernel<8, false, 0, kDqLanesK, true>, grid, block, stream, p, g_idx);
+    default: return XBIT_ERR_BITS;
+  }
+}
 
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream) {
   const bool aligned = ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 16 == 0) && ((uintptr_t)p.out % 16 == 0);

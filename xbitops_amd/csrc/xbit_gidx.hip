@@ -202,6 +202,27 @@ int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
 
 int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
   if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
+  {
+    // the contiguous-group tile kernel with per-row group ids (4096x11008 w4, shuffled ids: 76 -> see profiles/r03/gidx_dequant.txt)
+    const uint32_t kblocks = (p.k + 31u) / 32u;
+    const bool aligned = ((uintptr_t)p.qweight % 16 == 0) && ((uintptr_t)p.scales % 16 == 0) && ((uintptr_t)p.out % 16 == 0) && ((uintptr_t)p.g_idx % 4 == 0);
+    if (p.n % 8u == 0 && aligned && (kblocks + 3u) / 4u <= 65535u && p.groups >= 1u) {
+      DequantParams q{};
+      q.out = p.out;
+      q.qweight = p.qweight;
+      q.scales = p.scales;
+      q.qzeros = p.qzeros;
+      q.k = p.k;
+      q.n = p.n;
+      q.groupsize = 1u;  // not used by the by-id build
+      q.kw = p.kw;
+      q.groups = p.groups;
+      q.zw = p.zw;
+      q.bias = p.bias;
+      q.kblocks = kblocks;
+      return launch_dequant_by_id(q, p.g_idx, bits, stream);
+    }
+  }
   const uint64_t total = (uint64_t)p.k * (p.n / 2u);
   if ((total + 255) / 256 > 0x7FFFFFFFull) return XBIT_ERR_SHAPE;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);

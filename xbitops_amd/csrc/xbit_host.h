@@ -130,6 +130,8 @@ inline int pick_cpl(uint32_t n) {
 }
 
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
+// act-order dequant on the tile kernel (n % 8 == 0, 16-byte aligned qweight / scales / out, kblocks within the grid limit)
+int launch_dequant_by_id(const DequantParams& p, const int32_t* g_idx, int bits, hipStream_t stream);
 int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);          // dispatcher (xbit_gemv.hip)
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);     // xbit_gemv_mfma.hip
 // fused launch over p.multi_* (M = 1); XBIT_ERR_SHAPE when the shape is not eligible (caller then launches one by one)

@@ -19,6 +19,9 @@ from . import ops, packing
 # 128.  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM), so the fused one keeps
 # the lead up to about 128 rows.
 GEMV_MAX_ROWS = 128
+# General act-order layers (any g_idx): the library's fast path there takes rows four to a launch up to 16 rows (4096x11008
+# w4: 10.3 us at one row, 11.4 at four - profiles/r03/gidx_rows_1_2_4.txt); beyond that dequantise once and call the dense GEMM.
+GIDX_GEMV_MAX_ROWS = 16
 
 
 class QuantLinear(torch.nn.Module):
@@ -119,7 +122,7 @@ class QuantLinear(torch.nn.Module):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.in_features).to(torch.float16).contiguous()
         if self.g_idx is not None:  # general act-order: the group of row k is g_idx[k]
-            if x2.shape[0] <= GEMV_MAX_ROWS:
+            if x2.shape[0] <= GIDX_GEMV_MAX_ROWS:
                 y = ops.gemv_gidx(x2, self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.in_features, self.add_zero_bias)
             else:
                 y = x2 @ self.dequantize()
