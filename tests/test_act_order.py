@@ -101,7 +101,8 @@ def test_act_order_kernels_vs_oracle(bits, cuda_device):
     from xbitops_amd import ops
 
     for k, n, g, m, equal in ((4096, 256, 128, 1, True), (1000, 68, 40, 3, False), (8192, 64, 32, 2, True), (4096 + 64, 132, 128, 1, False),
-                              (96, 6, 16, 1, False)):
+                              (96, 6, 16, 1, False), (4096, 200, 128, 8, False), (8192, 96, 64, 16, True), (2048, 144, 128, 13, False),
+                              (4096, 64, 128, 40, True), (1000, 68, 40, 7, False)):  # 5..16 rows: the 8- / 16-row by-id builds; 40: 16 + 16 + 8
         p, g_idx = _act_order_problem(k, n, bits, g, m, 100 * bits + n, equal)
         a, qw, sc, qz, gi = _to_dev(cuda_device, p.act, p.qweight, p.scales, p.qzeros, g_idx)
         w = ops.dequant_gidx(qw, sc, qz, gi, bits, k, 1).cpu().numpy()
@@ -135,17 +136,18 @@ def test_quant_linear_act_order(equal, cuda_device):
     from xbitops_amd.linear import QuantLinear
 
     k, n, g, bits = 2048, 256, 128, 4
-    p, g_idx = _act_order_problem(k, n, bits, g, 20, 5, equal)
+    p, g_idx = _act_order_problem(k, n, bits, g, 140, 5, equal)
     layer = QuantLinear.from_act_order(p.qweight, p.scales, p.qzeros, g_idx, bits, g, add_zero_bias=1).to(cuda_device)
     assert (layer.perm is not None) == equal and (layer.g_idx is not None) == (not equal)
     w_ref = oracle.dequant_gidx(p.qweight, p.scales, p.qzeros, g_idx, bits, k, 1, oracle.RNE)
     assert np.array_equal(_bits(layer.dequantize().cpu().numpy()), _bits(w_ref))
-    for rows in (1, 4, 20):  # GEMV, skinny and dequant + GEMM paths
+    for rows in (1, 4, 20, 40, 140):  # fused kernel (one launch, several launches) and, at 140 rows, dequant + dense GEMM
         x = torch.from_numpy(p.act[:rows]).to(cuda_device)
         y = layer(x).cpu().numpy()
         y_ref = oracle.gemv_gidx(p.act[:rows], p.qweight, p.scales, p.qzeros, g_idx, bits, k, 1, oracle.RNE)
-        tol = 1e-3 if rows <= 16 else 2e-3  # > 16 rows: fp16 GEMM of the dequantised weight
-        assert (np.abs(y.astype(np.float64) - y_ref.astype(np.float64)) <= tol * np.abs(y_ref.astype(np.float64)) + 1e-3 * (rows > 16) + 2.0 ** -14).all(), rows
+        dense = rows > 128  # fp16 GEMM of the dequantised weight
+        tol = 2e-3 if dense else 1e-3
+        assert (np.abs(y.astype(np.float64) - y_ref.astype(np.float64)) <= tol * np.abs(y_ref.astype(np.float64)) + 1e-3 * dense + 2.0 ** -14).all(), rows
 
 
 @pytest.mark.gpu

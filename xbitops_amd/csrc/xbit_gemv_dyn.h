@@ -106,6 +106,7 @@ struct DynParams {
                             // group sizes that are no multiple of 32 (16, 48, 80 ...), where a group may begin inside a k-block
   uint64_t* trace;          // stamped build only
   bool by_id;               // host side only: launch the act-order build
+  uint32_t id_bytes;        // host side only: LDS bytes of the staged group ids (2 B per k of the range), 0 without by_id
 };
 
 // Template parameters
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(64 * NW)
                     uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, const int32_t* g_idx, uint64_t* trace) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX};
+  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
@@ -157,13 +158,14 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
   static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
-  static_assert(!WAVEACT || (NL == 16 && !SPLIT && !GIDX && FLAGS == 0), "8 / 16 rows: whole-K tiles of 16 lanes, contiguous groups");
+  static_assert(!WAVEACT || (NL == 16 && !SPLIT && FLAGS == 0), "8 / 16 / 32 rows: whole-K tiles of 16 lanes");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
   //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * MT * CN floats][bad flags: 8 dwords]
   uint32_t* const s_act = s_dyn;
   uint32_t* const s_gid = s_act + p.act_bytes / 4u;
-  uint32_t* const s_tab = s_gid + (GIDX ? p.act_bytes / (4u * MT) : 0u);  // ids: 2 B per k, whatever MT
+  const uint32_t id_dwords = GIDX ? p.ups * (uint32_t)((64 / NL) * UB * 16) : 0u;  // ids: 2 B per k of the range, whatever MT
+  uint32_t* const s_tab = s_gid + id_dwords;
   uint32_t* const s_tab_plain = s_tab + (GIDX ? p.tab_groups * (uint32_t)(NL * 4) : 0u);
   float* const s_red = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
   uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * MT * CN + 3) & ~3));
@@ -443,7 +445,23 @@ __global__ void __launch_bounds__(64 * NW)
           const uint32_t lo = d < 2 ? g_raw[r][0][2 * d] : g_raw[r][1][2 * d - 4], hi = d < 2 ? g_raw[r][0][2 * d + 1] : g_raw[r][1][2 * d - 3];
           o[d] = (lo < top ? lo : top) | ((hi < top ? hi : top) << 16);  // out-of-range (or negative) ids are clamped, never followed
         }
-        if (c * (16u * MT) < p.act_bytes) *reinterpret_cast<u32x4_t*>(s_gid + c * 4u) = o;
+        if (c * 4u < id_dwords) *reinterpret_cast<u32x4_t*>(s_gid + c * 4u) = o;
+      }
+      // a K beyond the static rounds (8 / 16-row builds: one build for every K): the rest one round at a time
+      for (uint32_t c = (uint32_t)(SI * ST + tid); c * 4u < id_dwords; c += (uint32_t)ST) {
+        const uint32_t top = p.groups - 1u;
+        uint32_t id[8];
+        if (p.g_idx != nullptr) {
+          const u32x4_t a0 = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u, 0, 0), a1 = __builtin_amdgcn_raw_buffer_load_b128(r_g, c * 32u + 16u, 0, 0);
+          id[0] = a0.x; id[1] = a0.y; id[2] = a0.z; id[3] = a0.w; id[4] = a1.x; id[5] = a1.y; id[6] = a1.z; id[7] = a1.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) id[j] = (c * 8u + (uint32_t)j) / p.gshift;
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = (id[2 * d] < top ? id[2 * d] : top) | ((id[2 * d + 1] < top ? id[2 * d + 1] : top) << 16);
+        *reinterpret_cast<u32x4_t*>(s_gid + c * 4u) = o;
       }
     }
   }
@@ -696,7 +714,7 @@ __global__ void __launch_bounds__(64 * NW)
 inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl, int mt) {
   const int hs = 16 / nl, cn = nl * cpl;
   // act-order: group ids (2 B per k) beside the activations and a second table for the spliced form
-  const size_t ids = p.by_id ? (size_t)p.act_bytes / (size_t)mt : 0u, tables = p.by_id ? 2u : 1u;
+  const size_t ids = p.by_id ? (size_t)p.id_bytes : 0u, tables = p.by_id ? 2u : 1u;
   return (size_t)p.act_bytes + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u + 32u;
 }
 
@@ -731,8 +749,11 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #else
   (void)stamped;
 #endif
-  if (p.by_id) {  // act-order: 48-column tiles, K up to 4096 (2 rounds) or 8192 (4 rounds), 1 or up to 4 rows
+  if (p.by_id) {  // act-order: 48-column tiles; 1 or up to 4 rows: K up to 4096 (2 rounds) or 8192 (4 rounds); 5..16 rows: any K
     if constexpr (NL == 16 && CPL == 3) {
+      if (p.m > 16u) return kDynNotEligible;
+      if (p.m > 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 16>(p, stream);
+      if (p.m > 4u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 8>(p, stream);
       if (p.m > 1u) {
         if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 4>(p, stream);
         if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, true, 4>(p, stream);
@@ -786,7 +807,8 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
   if (g.m < 1u || g.m > 32u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
-  if (g.m > 4u && (g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || nl != 16)) return kDynNotEligible;  // 5..16 rows: contiguous groups, whole K
+  if (g.m > 4u && (splits > 1u || nl != 16)) return kDynNotEligible;             // 5..32 rows: whole K, tiles of 16 lanes
+  if (g.m > 16u && (g_idx != nullptr || g.groupsize % 32u != 0u)) return kDynNotEligible;  // 17..32 rows: contiguous groups
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
   // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column
   // tiles, whole K, every group in the LDS table.
@@ -832,6 +854,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   const uint32_t mt = g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u)));
   p.act_bytes = p.ups * lk * UB * 64u * mt;
   if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
+  p.id_bytes = by_id ? p.ups * lk * UB * 64u : 0u;
   // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
   // launches cover at least `groups` rows so that the zero rows past the last group exist
   p.tab_groups = ((p.ups * lk - 1u + ((1u << p.gshift) - 1u)) >> p.gshift) + 1u;
@@ -846,7 +869,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   constexpr uint32_t st = 64u * kDynStagers;
   const uint32_t chunks = mt >= 8u ? 0u : p.act_bytes / mt / (uint32_t)(Unpack<BITS>::kChunkK * 2);  // a staging thread takes one chunk of every row per round
   const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
-  const uint32_t r_gid = by_id ? (p.act_bytes / mt / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round
+  const uint32_t r_gid = by_id && mt < 8u ? (p.id_bytes / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round (8 / 16 rows: beyond 2 rounds in a loop)
   const uint32_t r_tab_static = by_id ? 0u : r_tab;  // the by-id build stages table entries beyond its static rounds in a loop
   const uint32_t rounds = r_act > r_tab_static ? (r_act > r_gid ? r_act : r_gid) : (r_tab_static > r_gid ? r_tab_static : r_gid);
 #define XBIT_DYN(CPL_, NL_)                                                                      \

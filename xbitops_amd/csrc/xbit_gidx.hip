@@ -157,11 +157,11 @@ int launch_gemv_gidx_bits(const GemvGidxParams& p, hipStream_t stream) {
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
   if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
   if (p.m > 65535u) return XBIT_ERR_SHAPE;
-  // Up to 16 rows: the act-order build of the staged-operand kernel (xbit_gemv_dyn.h), four rows per launch - the weight
-  // stream and the arithmetic of the contiguous-group kernel plus a per-pair table lookup (4096x11008 w4, one row:
-  // 29.8 -> 10.0 us, 1.5x the contiguous kernel; profiles/r03/gidx_before.txt, gidx_after.txt).  More rows, very many
-  // groups or a K beyond its staging: the kernels of this file.
-  if (p.m <= 16u) {
+  // Up to 64 rows: the act-order builds of the staged-operand kernel (xbit_gemv_dyn.h), up to 16 rows per launch - the
+  // weight stream and the arithmetic of the contiguous-group kernel plus a per-pair table lookup (4096x11008 w4, one row:
+  // 29.8 -> 10.0 us, 1.5x the contiguous kernel; profiles/r03/gidx_before.txt, gidx_after.txt, gidx_rows_8_16.txt).  More
+  // rows, very many groups or a K beyond its staging: the kernels of this file.
+  if (p.m <= 64u) {
     GemvParams q{};
     q.qweight = p.qweight;
     q.scales = p.scales;
@@ -174,8 +174,8 @@ int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
     q.zw = p.zw;
     q.bias = p.bias;
     int st = kGemvDynNotEligible;
-    for (uint32_t r = 0; r < p.m; r += 4u) {
-      q.m = p.m - r < 4u ? p.m - r : 4u;
+    for (uint32_t r = 0; r < p.m; r += 16u) {
+      q.m = p.m - r < 16u ? p.m - r : 16u;
       q.a = p.a + (size_t)r * p.k;
       q.out = p.out + (size_t)r * p.n;
       st = launch_gemv_dyn(q, bits, stream, 3, 16, true, false, nullptr, 1, nullptr, p.g_idx);

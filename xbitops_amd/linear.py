@@ -19,9 +19,10 @@ from . import ops, packing
 # 128.  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM), so the fused one keeps
 # the lead up to about 128 rows.
 GEMV_MAX_ROWS = 128
-# General act-order layers (any g_idx): the library's fast path there takes rows four to a launch up to 16 rows (4096x11008
-# w4: 10.3 us at one row, 11.4 at four - profiles/r03/gidx_rows_1_2_4.txt); beyond that dequantise once and call the dense GEMM.
-GIDX_GEMV_MAX_ROWS = 16
+# General act-order layers (any g_idx): the library takes rows sixteen to a launch (4096x11008 w4: 10.4 us at one row, 11.9
+# at sixteen - profiles/r03/gidx_rows_8_16.txt); three launches (36 us) still beat the act-order dequant (25 us) plus the
+# dense GEMM (23 us and more), four do not.
+GIDX_GEMV_MAX_ROWS = 48
 
 
 class QuantLinear(torch.nn.Module):
