@@ -117,13 +117,13 @@ def _run_rows(lib, p, bias, dev):
 
 
 @pytest.mark.parametrize("bits", range(2, 9))
-def test_odd_group_sizes_one_to_four_rows(bits, cuda_device):
+def test_odd_group_sizes_one_to_sixteen_rows(bits, cuda_device):
     """Group sizes that are not a multiple of 32 (16, 48, 80, 1000, 17: a group may begin anywhere inside a k-block), one
-    to four rows: the staged-operand kernel's by-id build with the ids computed as k / groupsize (ragged K included at one
+    to sixteen rows: the staged-operand kernel's by-id builds with the ids computed as k / groupsize (ragged K included at one
     row; K = 4096 at group 16 is the largest table it takes: 256 groups)."""
     lib = _lib.load()
     for k, n, g, m in [(4096, 1024, 48, 1), (2048, 130, 16, 1), (7167, 512, 80, 1), (1000, 66, 1000, 3), (4096, 96, 16, 4), (96, 2, 16, 2),
-                       (1024, 4100, 17, 1), (8192, 48, 48, 2)]:
+                       (1024, 4100, 17, 1), (8192, 48, 48, 2), (2048, 256, 48, 9), (1000, 66, 1000, 6), (4096, 130, 80, 16)]:
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m))
@@ -131,10 +131,10 @@ def test_odd_group_sizes_one_to_four_rows(bits, cuda_device):
 
 @pytest.mark.parametrize("bits", range(2, 9))
 def test_column_kernel_shapes(bits, cuda_device):
-    """What no fast kernel takes - more than four rows of an odd group size, ragged K with several rows, more groups than
+    """What no fast kernel takes - more than sixteen rows of an odd group size, ragged K with several rows, more groups than
     the by-id table holds - runs the coalesced column kernel: exact W, fp32 sums."""
     lib = _lib.load()
-    for k, n, g, m in [(333, 64, 17, 5), (7167, 1024, 128, 4), (2048, 256, 48, 9), (1000, 66, 1000, 6), (8192, 130, 16, 1), (1001, 70, 80, 2)]:
+    for k, n, g, m in [(333, 64, 17, 5), (7167, 1024, 128, 4), (2048, 256, 48, 19), (1000, 66, 1000, 33), (8192, 130, 16, 1), (1001, 70, 80, 2)]:
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Shapes outside the fast path's alignment rules, beside their aligned neighbours: ragged K (K % 8 != 0, one row: the
 staged-operand kernel with a masked tail; several rows: the coalesced column kernel) and group sizes that are not a
-multiple of 32 (the staged-operand kernel's by-id build; the column kernel beyond four rows).  Period of a dependent chain of launches, cold HBM, production library.
+multiple of 32 (the staged-operand kernel's by-id builds; the column kernel beyond sixteen rows).  Period of a dependent chain of launches, cold HBM, production library.
     python tools/sweep_ragged.py [--bits 4,3]
 """
 import argparse
@@ -29,7 +29,9 @@ CASES = [  # (K, N, group, rows, note)
     (4096, 4096, 16, 1, "group 16: by-id build (256 groups: 128 KB of table)"),
     (4096, 11008, 48, 1, "group 48: by-id build, ids computed"),
     (4096, 4096, 48, 4, "group 48, 4 rows: by-id build"),
-    (4096, 4096, 48, 8, "group 48, 8 rows: column kernel"),
+    (4096, 4096, 48, 8, "group 48, 8 rows: by-id build (8-row)"),
+    (4096, 4096, 48, 16, "group 48, 16 rows: by-id build (16-row)"),
+    (4096, 4096, 48, 24, "group 48, 24 rows: column kernel"),
 ]
 
 

@@ -385,11 +385,11 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
 #endif
   if (mfma_ok) return launch_gemv_mfma(p, bits, stream, opts);
   // One row of any length k (the reference harness's own K = 7167, main.cc:21): the staged-operand kernel masks the tail
-  // of the activation vector itself.  Group sizes that are not a multiple of 32 (16, 48, 80 ...; one to four rows): the
-  // same kernel's by-id build, which looks every row's group up (ids computed as k / groupsize).  What is left for the
-  // column kernel below: ragged k with several rows, more than four rows of an odd group size, tensors that are not
+  // of the activation vector itself.  Group sizes that are not a multiple of 32 (16, 48, 80 ...; one to sixteen rows): the
+  // same kernel's by-id builds, which look every row's group up (ids computed as k / groupsize).  What is left for the
+  // column kernel below: ragged k with several rows, more than sixteen rows of an odd group size, tensors that are not
   // 4-byte aligned or reach 2 GiB (profiles/r03/sweep_ragged_shapes.txt).
-  if (p.m <= 4u && (p.m == 1u || p.k % 8u == 0u) && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
+  if (p.m <= 16u && (p.m == 1u || p.k % 8u == 0u) && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
     const int st = launch_gemv_dyn(p, bits, stream, pick_cpl(p.n), 16, true, false, nullptr);
     if (st != kGemvDynNotEligible) return st;
   }
