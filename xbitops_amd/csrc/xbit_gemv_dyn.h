@@ -1,5 +1,6 @@
-// xbit_gemv_dyn.h — A16Wx GEMV for one to four activation rows (decode), gfx950, bits 2..8: whole-K column tiles, small
-// operands staged once per workgroup by HALF of its waves while the other half already streams weights.
+// xbit_gemv_dyn.h — A16Wx GEMV for 1 to 32 activation rows (decode, speculative and small-batch decode), gfx950, bits 2..8:
+// whole-K column tiles, small operands staged once per workgroup by HALF of its waves while the other half already streams
+// weights; builds for 1 / 4 / 8 / 16 / 32 rows, split-K, act-order and odd group sizes (template parameters below).
 //
 // Same packed layout, same arithmetic and the same lane map as xbit_gemv_mfma.h (NL lanes x CPL adjacent columns,
 // 64 / NL k-slots per wave, a lane owns whole k-blocks, W rebuilt bit for bit in packed fp16, multiply-accumulate on
@@ -115,14 +116,16 @@ struct DynParams {
 //          MFMA's 16 column slots are 8 columns x 2 k-slots, kept apart by feeding their activations to row blocks 0-7
 //          and 8-15 of the A operand, as in xbit_gemv_mfma.h)                       NW   waves per workgroup
 //   SI     staging rounds (each staging thread handles SI activation chunks and SI table entries; their loads all go
-//          out up front): the launcher picks the smallest of 1, 2, 4, 8 that covers the shape
+//          out up front): the launcher picks the smallest of 2, 3, 4, 8 that covers the shape; the by-id and the 8- / 16- /
+//          32-row builds exist for SI = 2 (4) only and stage what is left in a loop
 //   STW    waves that stage the small operands (the first STW); the other NW - STW go straight to their weight rows
 //   LA     row lookahead (see Plan)
 //   FLAGS  2 = per-wave stamps to p.trace (measurement builds)
 //   SPLIT  split-K: workgroup (tile, split) sums units [split * ups, (split + 1) * ups) only and stages only that range's
 //          activations and groups; the partial sums meet in per-element 64-bit fixed-point accumulators exactly as in
 //          xbit_gemv_mfma.h (one returning atomic per element and workgroup; the last arriver converts, stores and clears)
-//   GIDX   act-order ("desc_act", quant_cuda_kernel.cu:257-336 in the reference): the group of row k is g_idx[k].  The ids
+//   GIDX   groups by id: act-order ("desc_act", quant_cuda_kernel.cu:257-336 in the reference: the group of row k is g_idx[k]),
+//          or - g_idx null - contiguous groups of a size that is no multiple of 32, ids computed as k / groupsize.  The ids
 //          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
 //          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
 //          column more than the contiguous build, no change to the weight stream.

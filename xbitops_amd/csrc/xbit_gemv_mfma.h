@@ -1,4 +1,7 @@
-// xbit_gemv_mfma.h — the production A16Wx GEMV / skinny-GEMM kernel (M = 1..16 per pass) for gfx950.
+// xbit_gemv_mfma.h — the A16Wx GEMV / skinny-GEMM kernel of rounds 1-2 (M = 1..16 per pass) for gfx950, and the launch
+// rules that choose between it and the staged-operand kernel of round 3 (xbit_gemv_dyn.h; launch_bits below).  This kernel
+// still serves the 128-column-tile shapes, 160-tile layers, the measured split plans, fused multi-set launches, few-column
+// layers beyond one row and everything over 128 rows; DESIGN.md section 3.0 has the table.
 //
 // A workgroup owns a column tile over all of K (or one K range of it: split-K); lanes own whole
 // 32-k blocks of CPL adjacent columns; the packed rows of a lane are loaded a few rows ahead of the
