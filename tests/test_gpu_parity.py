@@ -495,9 +495,9 @@ def test_gemv_split_k_shapes(bits, cuda_device):
 
 @pytest.mark.parametrize("bits,k,n", [(4, 11008, 4096), (4, 13824, 2560), (3, 13824, 2560), (2, 11008, 4096)])
 def test_gemv_measured_plan_shapes(bits, k, n, cuda_device):
-    """Down-projection shapes that take a measured split plan (kTunedPlans in xbit_gemv_mfma.h: 32-column tiles,
-    six K ranges, 4-5-wave workgroups) instead of the scored one: full size against the oracle, bit-stable across
-    launches, and equal up to summation order to the unsplit launch and to a forced other plan."""
+    """Down-projection shapes whose K is not a power of two (round 2 kept a table of measured split plans for them; round 3
+    splits them by the fill-the-chip-once rule like every few-column long-K layer): full size against the oracle, bit-stable
+    across launches, and equal up to summation order to the unsplit launch and to a forced other plan."""
     import XbitOps
     from xbitops_amd import ops
 

@@ -647,29 +647,6 @@ struct SplitPlan {
   int cpl = 0;
   uint32_t splits = 0;
 };
-// Shapes where a measured plan beats the scored one by >= 5 % (one row, g128; profiles/r02/sweep_split_plans_fine.txt:
-// every split factor 2..12 x both tile widths on 14 small-N shapes, 4-bit - on the other 11 the score is within 2.6 %
-// of the best - and sweep_split_plans_2_3_bit.txt for the same three shapes at 2 and 3 bits).  All are down-projections
-// whose K is not a power of two: 32-column tiles x six to eight K ranges of 14-18 batches run as 4-5-wave workgroups,
-// three or more per CU, where the score would take wide tiles with 4-6 waves per CU.
-struct TunedPlan {
-  int bits;
-  uint32_t k, n;
-  int cpl;
-  uint32_t splits;
-};
-constexpr TunedPlan kTunedPlans[] = {
-    {4, 11008, 4096, 2, 6},  // Llama-7B down_proj:         7.64 us against 8.28
-    {4, 13824, 5120, 2, 6},  // Llama-13B down_proj:       10.52 against 11.12
-    {4, 13824, 2560, 2, 6},  // ... its 2-way column shard:  7.20 against 8.00
-    {3, 11008, 4096, 2, 6},  //  7.28 against 8.20
-    {3, 13824, 5120, 2, 8},  //  9.52 against 10.48 (six ranges of 5-wave workgroups: 10.9)
-    {3, 13824, 2560, 2, 8},  //  6.96 against 7.76
-    {2, 11008, 4096, 2, 6},  //  6.76 against 7.72
-    {2, 13824, 5120, 2, 7},  //  8.60 against 9.68
-    {2, 13824, 2560, 2, 7},  //  6.52 against 7.40
-};
-
 // Waves of a split-K workgroup that fit on one CU: 4 SIMDs x (512 VGPRs / the build's allocation).  The wide-word
 // unpackers are register-hungry (7-bit, 64-column tiles: 170 VGPRs = two waves per SIMD), and a plan whose workgroups
 // do not all fit on the chip at once runs in rounds: 5-bit 11008x4096 took 14.6 us with nine K ranges of 5-wave
@@ -687,14 +664,6 @@ inline uint32_t split_waves_per_cu(int bits, int cpl, uint32_t m) {
 inline SplitPlan plan_split(const GemvParams& p, int ub, int forced_splits, int bits = 0) {
   SplitPlan plan;
   if (p.m > 4 || forced_splits == 1) return plan;
-  if (forced_splits == 0 && p.m == 1 && p.groupsize % 128u == 0) {  // measured at g128; g256 runs the same launches (checked: 11008x4096 8.1 -> 7.6 us)
-    for (const TunedPlan& t : kTunedPlans)
-      if (t.bits == bits && t.k == p.k && t.n == p.n) {
-        plan.cpl = t.cpl;
-        plan.splits = t.splits;
-        return plan;
-      }
-  }
   const uint32_t kblocks = (p.k + 31) / 32, batches = (kblocks + ub - 1) / ub;
   const uint32_t tiles32 = (p.n + 31) / 32;
   if (forced_splits > 0) {
@@ -1006,6 +975,31 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     }
 #endif  // XBIT_TUNING
     // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
+    // One row: FILL THE CHIP ONCE - 64-column tiles of the staged-operand kernel's split-K build times as many K ranges as
+    // give at most 256 workgroups (32-column tiles where that would take more than 15 ranges: N around 1024).  An exhaustive
+    // sweep (every split factor 2..12 x both tile widths x both kernels; 41 shapes with K 8192..28672 and N 1024..5120 at 4
+    // bits, 16 each at 2 / 3 / 5 / 8 bits; profiles/r03/sweep_split_*.txt) puts this plan at the best one on most shapes
+    // and within 10 % on all, where round 2's scored planner plus its table of three measured shapes was up to 1.3 x (4-bit)
+    // and 1.95 x (5-bit 20480x2560: 17.3 against 8.9 us) off.  It also beats the table's own entries (11008x4096 w4 7.52
+    // against 7.83 us, 13824x2560 6.58 against 7.38), so the table is gone.
+    if (opts.split == 0 && p.m == 1u && variant <= 0 && kblocks >= 256u && (p.n + 31u) / 32u <= 176u &&
+        !(BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // 2- and 3-bit at K <= 8192 with >= 3072 columns: unsplit is as good or better (below)
+      const uint32_t t64 = (p.n + 63u) / 64u, t32 = (p.n + 31u) / 32u;
+      int fcpl = 4;
+      uint32_t fsplits = 256u / t64;
+      if (fsplits > 15u) {
+        fcpl = 2;
+        fsplits = 256u / t32 > 15u ? 15u : 256u / t32;
+      }
+      if (fsplits >= 2u) {
+        const size_t slots = (size_t)(fcpl == 4 ? t64 : t32) * (size_t)(16 * fcpl);
+        GemvWorkspace ws;
+        if (gemv_workspace(stream, slots, opts, &ws)) {
+          const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
+          if (st != kGemvDynNotEligible) return st;
+        }
+      }
+    }
     {
       SplitPlan plan = plan_split(p, UBMAX, opts.split, BITS);
       // 2- and 3-bit at K <= 8192 with >= 3072 columns: the unsplit staged-operand kernel on 16-column tiles beats every
