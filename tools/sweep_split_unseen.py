@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--bits", default="4")
     ap.add_argument("--ks", default="10240,12288,16384,20480")
     ap.add_argument("--ns", default="2048,3072,4096,5120")
+    ap.add_argument("--verbose", action="store_true", help="also print every (variant, split factor) time")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib, tun = _lib.load(), _lib.load_tuning()
@@ -36,6 +37,7 @@ def main():
                 best, how = unsplit, "unsplit"
                 fill = max(2, 256 // ((n + 63) // 64))  # 64-column tiles x as many K ranges as fill the chip once
                 t_fill = None
+                table = {}
                 for v in (202, 205, 332, 334):
                     for sp in sorted(set((2, 3, 4, 5, 6, 7, 8, 10, 12, fill))):
                         if sp > 15:
@@ -46,12 +48,16 @@ def main():
                             continue
                         if v == 334 and sp == fill:
                             t_fill = t
+                        table.setdefault(v, []).append("%d:%.2f" % (sp, t))
                         if t < best:
                             best, how = t, "variant %d split %d" % (v, sp)
                 auto = min(auto, gemv_sweep.gemv_case(lib, dev, k, n, bits, 128, 1, True, 60, -1, 0)[2])  # once more at the end: the first case of a shape reads a few per cent high
                 worst = max(worst, auto / best)
                 print("w%d %6dx%-5d  auto %6.2f  unsplit %6.2f  best %6.2f (%s)  auto/best %.3f   fill-once (334 x %d) %s" % (
                     bits, k, n, auto, unsplit, best, how, auto / best, fill, "%6.2f = %.3f of best" % (t_fill, t_fill / best) if t_fill else "n/a"), flush=True)
+                if args.verbose:
+                    for v in sorted(table):
+                        print("      variant %d  %s" % (v, "  ".join(table[v])), flush=True)
     print("# worst automatic / best: %.3f" % worst)
 
 

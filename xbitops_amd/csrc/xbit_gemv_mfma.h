@@ -982,22 +982,43 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     // and within 10 % on all, where round 2's scored planner plus its table of three measured shapes was up to 1.3 x (4-bit)
     // and 1.95 x (5-bit 20480x2560: 17.3 against 8.9 us) off.  It also beats the table's own entries (11008x4096 w4 7.52
     // against 7.83 us, 13824x2560 6.58 against 7.38), so the table is gone.
-    if (opts.split == 0 && p.m == 1u && variant <= 0 && kblocks >= 256u && (p.n + 31u) / 32u <= 176u &&
+    // Up to 8192 columns when K >= 12288 (8192 x N stays unsplit there: 8.8 against 9.0 us at N = 6144).  When one round of
+    // workgroups would leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192), two rounds are filled
+    // instead (x 5 = 480): 28672x6144 24.8 -> 20.3 us, 12288x6144 12.2 -> 10.9 (sweep_split_wide_shapes_*.txt).
+    const uint32_t t32_ = (p.n + 31u) / 32u;
+    if (opts.split == 0 && p.m == 1u && variant <= 0 && ((kblocks >= 256u && t32_ <= 176u) || (kblocks >= 384u && t32_ <= 256u)) &&
         !(BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // 2- and 3-bit at K <= 8192 with >= 3072 columns: unsplit is as good or better (below)
-      const uint32_t t64 = (p.n + 63u) / 64u, t32 = (p.n + 31u) / 32u;
+      const uint32_t t64 = (p.n + 63u) / 64u;
       int fcpl = 4;
-      uint32_t fsplits = 256u / t64;
-      if (fsplits > 15u) {
+      uint32_t tiles = t64, fsplits = 256u / t64;
+      if (fsplits > 15u) {  // narrow layers: 32-column tiles
         fcpl = 2;
-        fsplits = 256u / t32 > 15u ? 15u : 256u / t32;
+        tiles = t32_;
+        fsplits = 256u / t32_ > 15u ? 15u : 256u / t32_;
       }
-      if (fsplits >= 2u) {
-        const size_t slots = (size_t)(fcpl == 4 ? t64 : t32) * (size_t)(16 * fcpl);
+      uint32_t alt = 0;  // the one-round plan, tried if the two-round one is not eligible (K ranges too short)
+      if (tiles * fsplits < 205u && 512u / tiles <= 15u && tiles * (512u / tiles) >= 410u) {
+        alt = fsplits;
+        fsplits = 512u / tiles;
+      }
+      for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
+        const size_t slots = (size_t)tiles * (size_t)(16 * fcpl);
         GemvWorkspace ws;
         if (gemv_workspace(stream, slots, opts, &ws)) {
           const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
           if (st != kGemvDynNotEligible) return st;
+          // K ranges beyond the split build's staging rounds (K / splits > 4096 at group 128): the same plan on this file's
+          // split kernel (28672x8192: 26.4 unsplit, 24.6 split)
+          const uint32_t batches = (kblocks + UBMAX - 1u) / UBMAX;
+          if (attempt == 0 && fsplits <= batches / 8u) {
+            SplitPlan fp;
+            fp.cpl = fcpl;
+            fp.splits = fsplits;
+            return launch_plan<BITS, UBMAX>(p, stream, fp, ws);
+          }
         }
+        fsplits = alt;
+        alt = 0;
       }
     }
     {
