@@ -34,7 +34,7 @@ Printed JSON (one line, rank 0)
                        launches of the timed region; `isolated_launch_avg_kernel_us` is the same kernel launched on
                        an idle chip (host wait after every launch).  peak = 8000 GB/s (HBM3E spec).
                        `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/
-                       when they were taken from THIS build of the library (sha256 match), else null.
+                       when they were taken from THESE kernel sources (src_sha256 match), else null.
   cpu_baseline         (N = 1) the oracle's C restatement (fused dequant + GEMV, OpenMP) for ~10 s, and
                        the torch-CPU path (int32 shift/mask unpack -> fp16 W -> a @ W) timed as
                        unpack + matmul and matmul alone, thread counts stated.  Reported, not a target.
@@ -172,10 +172,29 @@ def lib_sha256(path: str) -> str:
     return h.hexdigest()
 
 
+def source_sha256() -> str:
+    """Identity of the native code that is running: the kernel sources and the flags they are compiled with.  (The bytes of
+    the built library are not one: a box that rebuilds it - tests/conftest.py does when the object files did not travel -
+    embeds its own paths.)"""
+    from xbitops_amd import build as hip_build
+
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(hip_build.CSRC)):
+        path = os.path.join(hip_build.CSRC, name)
+        if os.path.isfile(path) and name.endswith((".h", ".hip", ".cc")):
+            h.update(name.encode())
+            with open(path, "rb") as f:
+                h.update(f.read())
+    with open(os.path.join(ROOT, "include", "xbitops_hip.h"), "rb") as f:
+        h.update(f.read())
+    h.update(" ".join(hip_build.CXXFLAGS).encode())
+    return h.hexdigest()
+
+
 def offline_profile(workload_key: str, this_lib_sha: str):
     """rocprofv3 numbers committed under profiles/rNN/ for this workload (collected offline: counters
-    cannot be read in-process).  `matches_this_build` says whether they were taken from the library
-    that is running now; only then do they appear in `roofline`."""
+    cannot be read in-process).  `matches_this_build` says whether they were taken from the kernel sources
+    that are running now (source_sha256); only then do they appear in `roofline`."""
     best = None
     for root, _dirs, files in sorted(os.walk(os.path.join(ROOT, "profiles"))):
         if "pmc_traffic.json" not in files:
@@ -188,7 +207,7 @@ def offline_profile(workload_key: str, this_lib_sha: str):
             continue
         if rec.get("workload") != workload_key:
             continue
-        cand = dict(rec, source=os.path.relpath(path, ROOT), matches_this_build=rec.get("lib_sha256") == this_lib_sha)
+        cand = dict(rec, source=os.path.relpath(path, ROOT), matches_this_build=rec.get("src_sha256") == this_lib_sha)
         if best is None or cand["matches_this_build"] or not best["matches_this_build"]:
             best = cand  # later rounds win; a record of this very build wins over everything
     return best
@@ -494,7 +513,8 @@ def main(argv=None):
         achieved = nbytes / (cold_avg * 1e-3) / 1e9
         value = world * nbytes * K / dt / 1e9
         sha = lib_sha256(_lib.TUNING_LIB_PATH if gemv_opts is not None else _lib.LIB_PATH)
-        off = offline_profile(workload if world == 1 else "", sha) if cfg_name != "shape" else None
+        src_sha = source_sha256()
+        off = offline_profile(workload if world == 1 else "", src_sha) if cfg_name != "shape" else None
         traffic = off["traffic_bytes_per_launch"] if off and off.get("matches_this_build") else None
         rec = {
             "metric": ("dequant W%d GB/s at %dx%d g%d (bytes read + written / time; cold HBM)" % (bits, k_in, n_full, group)) if args.op == "dequant" else
@@ -542,6 +562,7 @@ def main(argv=None):
             "tok_per_s_proxy": round(achieved * 1e9 / 3.37e9, 1) if cfg_name == "cfg2" else None,
             "tok_per_s_formula": "roofline.achieved GB/s / 3.37 GB of w4g128 linear weights per token of a 7B model",
             "lib_sha256": sha,
+            "src_sha256": src_sha,
         }
         if warm is not None:
             warm_avg = sum(warm) / len(warm)

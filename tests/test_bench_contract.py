@@ -37,7 +37,7 @@ def _check_round2(rec):
     roof = rec["roofline"]
     assert roof["launches"] >= 200
     assert "host_clock_ms_per_step" in rec and "boundary_us_per_step" in rec
-    assert "offline_profile" in rec and "lib_sha256" in rec
+    assert "offline_profile" in rec and "lib_sha256" in rec and "src_sha256" in rec
     if roof["traffic"] is not None:
         assert rec["offline_profile"]["matches_this_build"] is True
 

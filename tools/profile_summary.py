@@ -83,6 +83,7 @@ def main(out):
             "workload": bench["config"]["workload"],
             "kernel": kernel,
             "lib_sha256": bench.get("lib_sha256"),
+            "src_sha256": bench.get("src_sha256"),
             "command": "tools/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu --steps 60 --warmup 10 ...",
             "raw": {"FETCH_SIZE": {"launches": len(fetch), "mean_KB": statistics.mean(fetch), "min_KB": min(fetch), "max_KB": max(fetch)},
                     "WRITE_SIZE": {"launches": len(write), "mean_KB": statistics.mean(write), "min_KB": min(write), "max_KB": max(write)}},

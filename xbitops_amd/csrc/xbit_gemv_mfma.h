@@ -1078,7 +1078,9 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       // (4096x4096 w4 7.3 -> 6.5 us, 8192x3584 12.2 -> 11.0).
       // Not long K on few tiles (13824x5120, 160 tiles: 17.3 -> 19.2 us at 8 rows - this file's passes run up to 14 waves
       // per workgroup there; sweep_rows_5_16_rule_check_before_long_k_exclusion.txt).
-      rows16_rule = p.m > 4u && p.m <= 16u && !(small_n && p.m <= 8u) && !(wide && p.m <= 8u) && (dyn_tiles >= 192u || kblocks <= 256u);
+      // Checked on shapes no earlier sweep held (profiles/r03/sweep_rows_unseen_shapes.txt): 192 tiles with a long K lose a
+      // few per cent (16384x6144 w4 at 8 rows: 19.1 against 19.8), hence 224.
+      rows16_rule = p.m > 4u && p.m <= 16u && !(small_n && p.m <= 8u) && !(wide && p.m <= 8u) && (dyn_tiles >= 224u || kblocks <= 256u);
       // Seventeen to thirty-two rows (the 32-row build: two A operands per unpacked B fragment, against two 16-row passes
       // that unpack every weight twice): 4096x11008 w4 15.2 -> 11.5 us at 32 rows, 5120x13824 26.8 -> 16.3, 8192x8192 22.7 ->
       // 16.8, 8192x28672 62 -> 43; not on few tiles (4096x4096 7.4 -> 8.6, 11008x4096 16.3 -> 21.1;
@@ -1099,7 +1101,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       }
       const bool wins = p.m > 16u ? (rows32_rule && p.m <= 32u)
                         : p.m > 4u ? rows16_rule
-                        : p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 192u)
+                        : p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 224u)  // 192 tiles (N = 6144) lose 5-7 % at K >= 6144
                                    : small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
       if ((wins && (!wide || p.m > 8u)) || (XBIT_TUNING && variant >= 300)) {
         const int st = try_dyn(cpl, small_n && p.m <= 8u);
