@@ -886,6 +886,58 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
 #endif
     return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, nt, stamped, opts.trace);
   };
+  // ---- split-K plan for one row on few-column, long-K layers (called from the group-size branches below) ----
+  // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
+  // One row: FILL THE CHIP ONCE - 64-column tiles of the staged-operand kernel's split-K build times as many K ranges as
+  // give at most 256 workgroups (32-column tiles where that would take more than 15 ranges: N around 1024).  An exhaustive
+  // sweep (every split factor 2..12 x both tile widths x both kernels; 41 shapes with K 8192..28672 and N 1024..5120 at 4
+  // bits, 16 each at 2 / 3 / 5 / 8 bits; profiles/r03/sweep_split_*.txt) puts this plan at the best one on most shapes
+  // and within 10 % on all, where round 2's scored planner plus its table of three measured shapes was up to 1.3 x (4-bit)
+  // and 1.95 x (5-bit 20480x2560: 17.3 against 8.9 us) off.  It also beats the table's own entries (11008x4096 w4 7.52
+  // against 7.83 us, 13824x2560 6.58 against 7.38), so the table is gone.
+  // Up to 8192 columns when K >= 12288 (8192 x N stays unsplit there: 8.8 against 9.0 us at N = 6144).  When one round of
+  // workgroups would leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192), two rounds are filled
+  // instead (x 5 = 480): 28672x6144 24.8 -> 20.3 us, 12288x6144 12.2 -> 10.9 (sweep_split_wide_shapes_*.txt).
+  auto fill_once = [&](auto ub_c) -> int {
+    constexpr int UB_ = decltype(ub_c)::value;
+    const uint32_t t32_ = (p.n + 31u) / 32u;
+    if (opts.split == 0 && p.m == 1u && variant <= 0 && ((kblocks >= 256u && t32_ <= 176u) || (kblocks >= 384u && t32_ <= 256u)) &&
+        !(BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // 2- and 3-bit at K <= 8192 with >= 3072 columns: unsplit is as good or better (below)
+      const uint32_t t64 = (p.n + 63u) / 64u;
+      int fcpl = 4;
+      uint32_t tiles = t64, fsplits = 256u / t64;
+      if (fsplits > 15u) {  // narrow layers: 32-column tiles
+        fcpl = 2;
+        tiles = t32_;
+        fsplits = 256u / t32_ > 15u ? 15u : 256u / t32_;
+      }
+      uint32_t alt = 0;  // the one-round plan, tried if the two-round one is not eligible (K ranges too short)
+      if (tiles * fsplits < 205u && 512u / tiles <= 15u && tiles * (512u / tiles) >= 410u) {
+        alt = fsplits;
+        fsplits = 512u / tiles;
+      }
+      for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
+        const size_t slots = (size_t)tiles * (size_t)(16 * fcpl);
+        GemvWorkspace ws;
+        if (gemv_workspace(stream, slots, opts, &ws)) {
+          const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
+          if (st != kGemvDynNotEligible) return st;
+          // K ranges beyond the split build's staging rounds (K / splits > 4096 at group 128): the same plan on this file's
+          // split kernel (28672x8192: 26.4 unsplit, 24.6 split)
+          const uint32_t batches = (kblocks + (uint32_t)UB_ - 1u) / (uint32_t)UB_;
+          if (attempt == 0 && fsplits <= batches / 8u) {
+            SplitPlan fp;
+            fp.cpl = fcpl;
+            fp.splits = fsplits;
+            return launch_plan<BITS, UB_>(p, stream, fp, ws);
+          }
+        }
+        fsplits = alt;
+        alt = 0;
+      }
+    }
+    return kGemvDynNotEligible;
+  };
   if (p.groupsize % (32u * UBMAX) == 0) {
 #if XBIT_TUNING
     if (variant == 180 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 1024>(p, stream);  // 16-row pass, weights first
@@ -974,52 +1026,11 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       }
     }
 #endif  // XBIT_TUNING
-    // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
-    // One row: FILL THE CHIP ONCE - 64-column tiles of the staged-operand kernel's split-K build times as many K ranges as
-    // give at most 256 workgroups (32-column tiles where that would take more than 15 ranges: N around 1024).  An exhaustive
-    // sweep (every split factor 2..12 x both tile widths x both kernels; 41 shapes with K 8192..28672 and N 1024..5120 at 4
-    // bits, 16 each at 2 / 3 / 5 / 8 bits; profiles/r03/sweep_split_*.txt) puts this plan at the best one on most shapes
-    // and within 10 % on all, where round 2's scored planner plus its table of three measured shapes was up to 1.3 x (4-bit)
-    // and 1.95 x (5-bit 20480x2560: 17.3 against 8.9 us) off.  It also beats the table's own entries (11008x4096 w4 7.52
-    // against 7.83 us, 13824x2560 6.58 against 7.38), so the table is gone.
-    // Up to 8192 columns when K >= 12288 (8192 x N stays unsplit there: 8.8 against 9.0 us at N = 6144).  When one round of
-    // workgroups would leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192), two rounds are filled
-    // instead (x 5 = 480): 28672x6144 24.8 -> 20.3 us, 12288x6144 12.2 -> 10.9 (sweep_split_wide_shapes_*.txt).
-    const uint32_t t32_ = (p.n + 31u) / 32u;
-    if (opts.split == 0 && p.m == 1u && variant <= 0 && ((kblocks >= 256u && t32_ <= 176u) || (kblocks >= 384u && t32_ <= 256u)) &&
-        !(BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // 2- and 3-bit at K <= 8192 with >= 3072 columns: unsplit is as good or better (below)
-      const uint32_t t64 = (p.n + 63u) / 64u;
-      int fcpl = 4;
-      uint32_t tiles = t64, fsplits = 256u / t64;
-      if (fsplits > 15u) {  // narrow layers: 32-column tiles
-        fcpl = 2;
-        tiles = t32_;
-        fsplits = 256u / t32_ > 15u ? 15u : 256u / t32_;
-      }
-      uint32_t alt = 0;  // the one-round plan, tried if the two-round one is not eligible (K ranges too short)
-      if (tiles * fsplits < 205u && 512u / tiles <= 15u && tiles * (512u / tiles) >= 410u) {
-        alt = fsplits;
-        fsplits = 512u / tiles;
-      }
-      for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
-        const size_t slots = (size_t)tiles * (size_t)(16 * fcpl);
-        GemvWorkspace ws;
-        if (gemv_workspace(stream, slots, opts, &ws)) {
-          const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
-          if (st != kGemvDynNotEligible) return st;
-          // K ranges beyond the split build's staging rounds (K / splits > 4096 at group 128): the same plan on this file's
-          // split kernel (28672x8192: 26.4 unsplit, 24.6 split)
-          const uint32_t batches = (kblocks + UBMAX - 1u) / UBMAX;
-          if (attempt == 0 && fsplits <= batches / 8u) {
-            SplitPlan fp;
-            fp.cpl = fcpl;
-            fp.splits = fsplits;
-            return launch_plan<BITS, UBMAX>(p, stream, fp, ws);
-          }
-        }
-        fsplits = alt;
-        alt = 0;
-      }
+    // Few column tiles, long K: split K over workgroups (needs the per-stream workspace); one row first tries the
+    // fill-the-chip-once plan (fill_once above).
+    {
+      const int st = fill_once(std::integral_constant<int, UBMAX>{});
+      if (st != kGemvDynNotEligible) return st;
     }
     {
       SplitPlan plan = plan_split(p, UBMAX, opts.split, BITS);
@@ -1136,6 +1147,10 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       // group size 64 at 2-4 bits: 2 k-blocks per lane.  Few column tiles and long K split here too (4-bit 11008x4096
       // g64: 10.5 us unsplit; profiles/r02/sweep_group_sizes.txt); the occupancy table is that of the 4-k-block builds,
       // which hold a few registers more (conservative)
+      {
+        const int st = fill_once(std::integral_constant<int, 2>{});  // one row: the same plan as at group size 128
+        if (st != kGemvDynNotEligible) return st;
+      }
       SplitPlan plan = (variant > 0 && variant != 398) ? SplitPlan{} : plan_split(p, 2, opts.split, BITS);
       if (plan.splits >= 2) {
         const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
@@ -1143,12 +1158,18 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
         GemvWorkspace ws;
         if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, 2>(p, stream, plan, ws);
       }
-      const int st = try_dyn(cpl, false);
-      if (st != kGemvDynNotEligible) return st;
+      // unsplit at group size 64 (profiles/r03/sweep_group_sizes_*.txt): the staged-operand kernel wins at 4 bits on many
+      // tiles (4096x11008 7.5 -> 7.3 us) and loses at 3 bits and on few tiles (4096x4096 w3 5.4 against 5.9)
+      if ((BITS == 4 && (p.n + 16u * cpl - 1) / (16u * cpl) >= 192u) || p.m > 1u || (XBIT_TUNING && variant >= 300)) {
+        const int st = try_dyn(cpl, false);
+        if (st != kGemvDynNotEligible) return st;
+      }
       return launch_cpl<BITS, 2>(p, stream, cpl);
     }
   }
-  {
+  // group size 32 (or 32 x odd): one table row per k-block - the staged-operand kernel loses 4-14 % at 3 and 4 bits
+  // (4096x11008 w3 7.6 against 8.7 us) and ties at 8
+  if (BITS >= 5 || p.m > 1u || (XBIT_TUNING && variant >= 300)) {
     const int st = try_dyn(cpl, false);
     if (st != kGemvDynNotEligible) return st;
   }
