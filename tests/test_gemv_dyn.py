@@ -180,6 +180,21 @@ def test_split_k_build_vs_oracle(bits, variant, cuda_device):
         assert np.array_equal(_bits(y), _bits(_run(lib, p, 1, cuda_device, variant)))  # arrival order does not matter: integer sums
 
 
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_fill_once_split_plans_production(bits, cuda_device):
+    """What the production library's split rule launches on few-column long-K layers: one round of 64-column tiles (an edge
+    tile included), 32-column tiles on a narrow layer, two rounds where one would leave the chip a fifth idle, a layer of 8192
+    columns at K >= 12288, K ranges too long for the split build (the same plan on the round-2 split kernel), group sizes 64
+    and 256; against the oracle, and bit-stable across launches."""
+    lib = _lib.load()
+    for k, n, g in [(8192, 1030, 128), (12288, 6150, 128), (16384, 520, 128), (28672, 3072, 128), (12288, 8192, 256), (11008, 4096, 64),
+                    (10240, 2560, 128)]:
+        p = synth.make_problem(k, n, bits, g, m=1, seed=bits * 19 + k + n)
+        y = _run_rows(lib, p, 1, cuda_device)
+        _close(y, _ref(p, 1), (bits, k, n, g))
+        assert np.array_equal(_bits(y), _bits(_run_rows(lib, p, 1, cuda_device)))
+
+
 def _run_m(lib, p, bias, dev, variant=-1):
     a, qw, sc, qz = (torch.from_numpy(x).to(dev) for x in (p.act, p.qweight, p.scales, p.qzeros))
     out = torch.full((p.m, p.n), float("nan"), dtype=torch.float16, device=dev)
