@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
   static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
-  static_assert(!WAVEACT || (NL == 16 && !SPLIT && FLAGS == 0), "8 / 16 / 32 rows: whole-K tiles of 16 lanes");
+  static_assert(!WAVEACT || (NL == 16 && FLAGS == 0), "8 / 16 / 32 rows: tiles of 16 lanes");
+  static_assert(!(SPLIT && MT == 32), "32 rows keep K whole");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
   //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * MT * CN floats][bad flags: 8 dwords]
@@ -769,7 +770,13 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
   }
   if (p.m > 4u) {  // 5..16 rows: the per-wave activation pipeline (8- and 16-row builds); the rounds stage the table only
     if constexpr (NL == 16) {
-      if (p.splits > 1u) return kDynNotEligible;
+      if (p.splits > 1u) {  // split-K (few-column long-K layers: down-projections at small batch), 64-column tiles
+        if constexpr (CPL == 4) {
+          if (p.m <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 8>(p, stream);
+          if (p.m <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 16>(p, stream);
+        }
+        return kDynNotEligible;
+      }
       if (p.m <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
       if (p.m <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
       return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
@@ -778,7 +785,13 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
   }
   if (p.m > 1u) {  // 2..4 rows: whole-K tiles of 16 lanes, K up to 4096 (2 rounds) or 8192 (4 rounds)
     if constexpr (NL == 16) {
-      if (p.splits > 1u) return kDynNotEligible;
+      if (p.splits > 1u) {
+        if constexpr (CPL == 4) {
+          if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 4>(p, stream);
+          if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, true, false, 4>(p, stream);
+        }
+        return kDynNotEligible;
+      }
       if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 4>(p, stream);
       if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, false, 4>(p, stream);
     }
@@ -810,7 +823,8 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
   if (g.m < 1u || g.m > 32u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
-  if (g.m > 4u && (splits > 1u || nl != 16)) return kDynNotEligible;             // 5..32 rows: whole K, tiles of 16 lanes
+  if (g.m > 4u && nl != 16) return kDynNotEligible;                              // 5..32 rows: tiles of 16 lanes
+  if (g.m > 16u && splits > 1u) return kDynNotEligible;                          // 17..32 rows keep K whole
   if (g.m > 16u && (g_idx != nullptr || g.groupsize % 32u != 0u)) return kDynNotEligible;  // 17..32 rows: contiguous groups
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
   // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column

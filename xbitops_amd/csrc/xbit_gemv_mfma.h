@@ -898,11 +898,16 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
   // Up to 8192 columns when K >= 12288 (8192 x N stays unsplit there: 8.8 against 9.0 us at N = 6144).  When one round of
   // workgroups would leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192), two rounds are filled
   // instead (x 5 = 480): 28672x6144 24.8 -> 20.3 us, 12288x6144 12.2 -> 10.9 (sweep_split_wide_shapes_*.txt).
+  // 2..16 rows take the same plan through the split-K builds of the 4-, 8- and 16-row kernels (down-projections at small
+  // batch): 11008x4096 w4 9.1 -> 7.9 us at 2 rows, 11.0 -> 8.3 at 8, 15.9 -> 9.6 at 16; 12288x3072 w8 at 16 rows 22.2 -> 11.3
+  // (profiles/r03/sweep_rows_split_k.txt; variant 336 forces it in tuning builds)
+  const bool fill_rows_rule = true;
   auto fill_once = [&](auto ub_c) -> int {
     constexpr int UB_ = decltype(ub_c)::value;
     const uint32_t t32_ = (p.n + 31u) / 32u;
-    if (opts.split == 0 && p.m == 1u && variant <= 0 && ((kblocks >= 256u && t32_ <= 176u) || (kblocks >= 384u && t32_ <= 256u)) &&
-        !(BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // 2- and 3-bit at K <= 8192 with >= 3072 columns: unsplit is as good or better (below)
+    const bool rows_ok = p.m == 1u || (XBIT_TUNING && variant == 336 && p.m <= 16u) || (fill_rows_rule && p.m <= 16u);
+    if (opts.split == 0 && rows_ok && (variant <= 0 || variant == 336) && ((kblocks >= 256u && t32_ <= 176u) || (kblocks >= 384u && t32_ <= 256u)) &&
+        !((p.m == 1u || (BITS == 2 && p.m <= 4u)) && BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // one row of 2 / 3 bits (2-bit: up to 4 rows) at K <= 8192 with >= 3072 columns: unsplit is as good or better (8192x3584 w2 at 2 rows: 6.1 against 6.8 us)
       const uint32_t t64 = (p.n + 63u) / 64u;
       int fcpl = 4;
       uint32_t tiles = t64, fsplits = 256u / t64;
@@ -917,11 +922,13 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
         fsplits = 512u / tiles;
       }
       for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
-        const size_t slots = (size_t)tiles * (size_t)(16 * fcpl);
+        const uint32_t mt_rows = p.m > 8u ? 16u : (p.m > 4u ? 8u : (p.m > 1u ? 4u : 1u));  // rows of the build that takes p.m
+        const size_t slots = (size_t)tiles * (size_t)(16 * fcpl) * mt_rows;
         GemvWorkspace ws;
         if (gemv_workspace(stream, slots, opts, &ws)) {
           const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
           if (st != kGemvDynNotEligible) return st;
+          if (p.m > 1u) break;  // several rows: no other kernel takes this plan
           // K ranges beyond the split build's staging rounds (K / splits > 4096 at group 128): the same plan on this file's
           // split kernel (28672x8192: 26.4 unsplit, 24.6 split)
           const uint32_t batches = (kblocks + (uint32_t)UB_ - 1u) / (uint32_t)UB_;
