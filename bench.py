@@ -34,7 +34,15 @@ Printed JSON (one line, rank 0)
                        launches of the timed region; `isolated_launch_avg_kernel_us` is the same kernel launched on
                        an idle chip (host wait after every launch).  peak = 8000 GB/s (HBM3E spec).
                        `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/
-                       when they were taken from THESE kernel sources (src_sha256 match), else null.
+                       when they were taken from THESE kernel sources AND this very library file (src_sha256 and
+                       lib_sha256 both match), else null.  `frac_isolated` is the same fraction by the timer of rounds
+                       1-2 (a host wait after every launch).  `read_floor_us` (one GPU): the period of a dependent chain
+                       of PURE READS of the same weight copies, measured in this very run through the measurement
+                       build's xbit_tuning_read_floor - `flat` (16-byte stream) and `tiles` (the column tiles the GEMV
+                       walks, same lane map, same workgroup order) - next to `kernel_chain_us`, the GEMV's own period
+                       measured the same way: what the memory system charges for the bytes alone on this box.
+  output_check         (one GPU, with the CPU leg) the output of the LAST timed step against the oracle under the GEMV
+                       contract (oracle/contract.py); dequant: bit-exact.
   cpu_baseline         (N = 1) the oracle's C restatement (fused dequant + GEMV, OpenMP) for ~10 s, and
                        the torch-CPU path (int32 shift/mask unpack -> fp16 W -> a @ W) timed as
                        unpack + matmul and matmul alone, thread counts stated.  Reported, not a target.
@@ -163,6 +171,31 @@ def cpu_baseline_torch(p, y_port, bits: int, g: int, k: int, nbytes: int, budget
     }
 
 
+def check_last_output(y_gpu, copy: int, qw_h, sc_h, qz_h, act_h, op: str, bits: int, g: int, k: int):
+    """The output of the last timed step (weight copy `copy`) against the oracle - the checker, on the host, after the timed
+    region.  Raises if the timed launches did not compute what they are credited for."""
+    import numpy as np
+
+    import oracle
+    from oracle import contract
+
+    qw = (qw_h.view(np.uint32) ^ np.uint32(0x01010101 * (copy % 127))).view(np.int32)  # the copy's contents (see `qws` in main)
+    qz = (qz_h.view(np.uint32) ^ np.uint32(0x11111111 * (copy % 13))).view(np.int32)
+    if op == "dequant":
+        w_ref = oracle.dequant(qw, sc_h, qz, g, bits, k, 1, oracle.RNE)
+        same = np.array_equal(np.ascontiguousarray(y_gpu).view(np.uint16), w_ref.view(np.uint16))
+        if not same:
+            raise SystemExit("bench.py: the last timed dequant is NOT bit-exact against the oracle")
+        return {"checked": "last timed step (weight copy %d), dequant, bit-exact against oracle.dequant (RNE)" % copy, "ok": True}
+    y_ref = oracle.gemv(act_h, qw, sc_h, qz, g, bits, k, 1, oracle.RNE)
+    why = contract.gemv_mismatch(np.ascontiguousarray(y_gpu), y_ref, k)
+    if why is not None:
+        raise SystemExit("bench.py: the last timed GEMV does not match the oracle: " + why)
+    err = np.abs(y_gpu.astype(np.float64) - y_ref.astype(np.float64))
+    return {"checked": "last timed step (weight copy %d) against oracle.gemv (RNE) under oracle/contract.py" % copy, "ok": True,
+            "max_abs_err": float(err.max()), "outputs": int(y_ref.size)}
+
+
 # ------------------------------------------------------------------------------------------------
 def lib_sha256(path: str) -> str:
     h = hashlib.sha256()
@@ -211,6 +244,23 @@ def offline_profile(workload_key: str, this_lib_sha: str):
         if best is None or cand["matches_this_build"] or not best["matches_this_build"]:
             best = cand  # later rounds win; a record of this very build wins over everything
     return best
+
+
+def floor_tile_shape(n: int, bits: int, batch: int):
+    """The column tiles the library's launch rule walks for an N-column layer at one row (for the pure-read floor): lane-map
+    width and columns owned per tile.  Mirrors the rule in xbit_gemv_mfma.h / xbit_host.h (pick_cpl, fill_tcols)."""
+    if bits in (4, 8) and n >= 25600 and batch <= 4:
+        tiles = -(-n // 128)
+        target = -(-tiles // 256) * 256
+        per = -(-n // target)
+        return 128, min(128, -(-per // 4) * 4)
+    best, best_eff = 32, -1.0
+    for cpl in (2, 3, 4):
+        tiles = -(-n // (16 * cpl))
+        eff = n / (16.0 * cpl) / (-(-tiles // 256) * 256)
+        if eff >= best_eff - 1e-9:
+            best, best_eff = 16 * cpl, eff
+    return best, 0
 
 
 def main(argv=None):
@@ -375,28 +425,34 @@ def main(argv=None):
         # and replayed, so that the timed region holds device time (kernel + collective) and not the host's ~5 us of
         # enqueue per GEMV plus torch's per-collective launch path.  If the collective cannot be captured on this stack
         # the region falls back to eager launches and says so.
+        # Capture first, replay later: a capture that fails on ONE rank must not leave the others inside K captured all-gathers
+        # while that rank waits in the all_reduce below (mismatched collectives hang).  So: both graphs are recorded without
+        # being replayed, the ranks agree, and only then does every rank run the untimed first replay - or none does.
+        g = gw = None
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 run_steps(W, K)
-            g.replay()  # the first replay of a graph pays a one-off ~40 us on the device: untimed
-            torch.cuda.synchronize()
-            graph = g
             if W > 0:  # the W warm-up steps as a graph of their own, replayed directly ahead of the timed one
                 gw = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gw):
                     run_steps(0, W)
-                gw.replay()
-                torch.cuda.synchronize()
-                warm_graph = gw
         except Exception as exc:  # noqa: BLE001 - any capture failure means "time it eagerly"
+            g = gw = None
             graph_note = "graph capture failed (%s: %s); eager launches" % (type(exc).__name__, str(exc).splitlines()[0][:160] if str(exc) else "")
             torch.cuda.synchronize()
-    ok = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank replays, or none does
-        if int(ok.item()) == 0 and graph is not None:
-            graph, warm_graph, graph_note = None, None, "graph capture failed on another rank; eager launches"
+        ok = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank replays, or none does
+        if int(ok.item()) == 1:
+            graph, warm_graph = g, gw  # assigned together: the note below always matches what runs
+            graph.replay()  # the first replay of a graph pays a one-off ~40 us on the device: untimed
+            if warm_graph is not None:
+                warm_graph.replay()
+            torch.cuda.synchronize()
+        elif g is not None:
+            graph_note = "graph capture failed on another rank; eager launches"
+        del g, gw
 
     stream = torch.cuda.current_stream(dev)
     blocker_cycles = 0
@@ -430,6 +486,8 @@ def main(argv=None):
     barrier()
     dt_host = time.perf_counter() - t0
     dt = ev0.elapsed_time(ev1) * 1e-3
+    last_step = W + K - 1  # its output is checked against the oracle below (before anything overwrites the buffer)
+    last_out_host = outs[last_step % n_out_bufs].cpu().numpy() if (world == 1 and not args.no_cpu) else None
     if world > 1:
         t = torch.tensor([dt, dt_host], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -497,6 +555,54 @@ def main(argv=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         collective_us = float(t.item())
 
+    # ---- pure-read floors, same run, same buffers, same clock (one GPU): the period of a dependent chain of launches
+    def chain_period_us(fn, n=200, reps=3):
+        out = []
+        for _r in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            if blocker_cycles:
+                torch.cuda._sleep(int((100 + 12 * n) * cycles_per_us))
+            e0.record(stream)
+            for i in range(n):
+                fn(W + K + i)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) * 1e3 / n)
+        return sorted(out)[len(out) // 2]
+
+    read_floor = None
+    if world == 1 and args.op == "gemv":
+        try:
+            tun = _lib.load_tuning()
+            tun.xbit_tuning_read_floor.restype = ctypes.c_int
+            tun.xbit_tuning_read_floor.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
+        except (_lib.XbitLibraryError, AttributeError) as exc:
+            tun, read_floor = None, {"note": "measurement build unavailable (%s)" % str(exc).splitlines()[0][:120]}
+        if tun is not None:
+            kw_rows = qws[0].shape[0]
+            pattern, tcols = floor_tile_shape(n_local, bits, batch)
+            sp = stream.cuda_stream
+
+            def floor_fn(pat, tc):
+                def fn(i):
+                    st = tun.xbit_tuning_read_floor(ptrs[i % copies][0], kw_rows, n_local, pat, tc, sp)
+                    if st != 0:
+                        raise RuntimeError("xbit_tuning_read_floor -> %d" % st)
+                return fn
+
+            floor_fn(0, 0)(0), floor_fn(pattern, tcols)(0)
+            torch.cuda.synchronize()
+            read_floor = {
+                "flat": round(chain_period_us(floor_fn(0, 0)), 3),
+                "tiles": round(chain_period_us(floor_fn(pattern, tcols)), 3),
+                "kernel_chain_us": round(chain_period_us(lambda i: kernel_step(i, sp)), 3),
+                "tile_lane_map_columns": pattern, "tile_columns": tcols or pattern,
+                "bytes_read": int(qws[0].numel() * 4),
+                "what": "period of 200 back-to-back launches behind a blocker (median of 3), cold weight copies: pure read of the packed rows - flat 16-byte stream / the GEMV's "
+                        "column tiles, all loads up front, no arithmetic - and the GEMV itself by the same clock; scales, zero-points, activations and outputs are not read by the floors",
+            }
+
     profiled_chain(8, True)
     cold = profiled_chain(max(MIN_ROOFLINE_LAUNCHES, args.roofline_launches), True)
     warm = profiled_chain(200, False) if args.warm else None
@@ -515,7 +621,7 @@ def main(argv=None):
         sha = lib_sha256(_lib.TUNING_LIB_PATH if gemv_opts is not None else _lib.LIB_PATH)
         src_sha = source_sha256()
         off = offline_profile(workload if world == 1 else "", src_sha) if cfg_name != "shape" else None
-        traffic = off["traffic_bytes_per_launch"] if off and off.get("matches_this_build") else None
+        traffic = off["traffic_bytes_per_launch"] if off and off.get("matches_this_build") and off.get("lib_sha256") == sha else None
         rec = {
             "metric": ("dequant W%d GB/s at %dx%d g%d (bytes read + written / time; cold HBM)" % (bits, k_in, n_full, group)) if args.op == "dequant" else
                       "A16W%d GEMV GB/s at %dx%d g%d batch=%d (algorithmic bytes / time; cold HBM)" % (bits, k_in, n_full, group, batch),
@@ -557,6 +663,8 @@ def main(argv=None):
                 "launches": len(cold), "timer": "hipExtLaunchKernel start/stop events per launch, launches queued back to back (a dependent chain, as in the timed region), cold weights" + (
                     ", max over GPUs" if world > 1 else ""),
                 "isolated_launch_avg_kernel_us": round(1e3 * sum(isolated) / len(isolated), 3),
+                "frac_isolated": round(nbytes / (sum(isolated) / len(isolated) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),  # rounds 1-2's timer: a host wait after every launch
+                "read_floor_us": read_floor,
             },
             "offline_profile": off,
             "tok_per_s_proxy": round(achieved * 1e9 / 3.37e9, 1) if cfg_name == "cfg2" else None,
@@ -572,6 +680,7 @@ def main(argv=None):
             port, prob, y_port = cpu_baseline_port(args.cpu_seconds, k_in, n_local, bits, group, batch, nbytes)
             port["torch_cpu"] = cpu_baseline_torch(prob, y_port, bits, group, k_in, nbytes, args.cpu_seconds)
             rec["cpu_baseline"] = port
+            rec["output_check"] = check_last_output(last_out_host, last_step % copies, qw_h, sc_h, qz_h, act_h, args.op, bits, group, k_in)
         print(json.dumps(rec), flush=True)
     if world > 1 or force_pg:
         if world > 1:

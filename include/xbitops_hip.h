@@ -194,6 +194,23 @@ int xbit_profile_last_ms(float* ms);
 int xbit_profile_series_begin(int capacity);
 int xbit_profile_series_end(float* ms, int max_count, int* count);
 
+/* What WOULD be launched (not part of the reference's surface).  Between xbit_dry_run_begin() and xbit_dry_run_end()
+ * every entry point called by this host thread goes through its argument checks and its launch rule as usual, but each
+ * kernel launch is RECORDED instead of issued: nothing touches the device (it works on a machine without one; device
+ * pointers are never followed, so any non-null, suitably aligned values do), split-K scratch is not allocated.
+ * A record names the kernel by the offset of its host-side handle inside this library (`nm -C` maps it to the template
+ * instantiation), and carries grid, block and dynamic LDS bytes.  Used by tests/ and tools/check_rules.py to pin the
+ * launch rules to a table of shapes, and by callers who want to know which path a layer will take.
+ * xbit_dry_run_end writes the first min(records, max_count) records, their number to `*count`, and ends the dry run. */
+typedef struct xbit_launch_record {
+  uint64_t kernel_offset;     /* address of the kernel's host-side handle minus the load address of this library */
+  uint32_t grid[3], block[3];
+  uint32_t dynamic_lds_bytes;
+  uint32_t reserved;
+} xbit_launch_record;
+int xbit_dry_run_begin(void);
+int xbit_dry_run_end(xbit_launch_record* records, int max_count, int* count);
+
 #ifdef __cplusplus
 }
 #endif

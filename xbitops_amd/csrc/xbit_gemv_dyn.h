@@ -91,6 +91,8 @@ struct Plan {
 struct DynParams {
   const uint32_t* qweight;  // [kw, n]
   uint32_t n, tiles, kw, units;  // units = ceil(k-blocks / (LK * UB)): wave w works on units w, w + NW, ...
+  uint32_t tcols;           // columns a tile OWNS (<= NL * CPL, a multiple of CPL): tile t starts at column t * tcols; lanes whose columns lie beyond
+                            // load nothing.  Narrower than the lane map when that makes the tile count fill the chip (28672 columns: 256 tiles of 112)
   const uint16_t* a;        // fp16 [m, k]
   const uint16_t* scales;   // fp16 [groups, n]
   const uint32_t* qzeros;   // [groups, zw]
@@ -108,6 +110,8 @@ struct DynParams {
   uint64_t* trace;          // stamped build only
   bool by_id;               // host side only: launch the act-order build
   uint32_t id_bytes;        // host side only: LDS bytes of the staged group ids (2 B per k of the range), 0 without by_id
+  const GemvSets* sets;     // host side only: the weight sets of a fused launch (MULTI builds), else null
+  uint32_t mt;              // host side only: rows of the build that takes this launch (1, 4, 8, 16, 32; >= m)
 };
 
 // Template parameters
@@ -120,7 +124,10 @@ struct DynParams {
 //          32-row builds exist for SI = 2 (4) only and stage what is left in a loop
 //   STW    waves that stage the small operands (the first STW); the other NW - STW go straight to their weight rows
 //   LA     row lookahead (see Plan)
-//   FLAGS  2 = per-wave stamps to p.trace (measurement builds)
+//   FLAGS  2 = per-wave stamps to p.trace (measurement builds).  Ablations, compiled by tools/microbench/gemv_lab.hip ONLY (they do
+//          not compute the GEMV; the library never instantiates them): 4 = the staging waves load no small operand (constants go
+//          through the same staging code), 8 = no cross-wave sum (every wave stores its own partial sums), 16 = no unpack / MFMA
+//          (the rows are loaded and waited for, nothing is computed)
 //   SPLIT  split-K: workgroup (tile, split) sums units [split * ups, (split + 1) * ups) only and stages only that range's
 //          activations and groups; the partial sums meet in per-element 64-bit fixed-point accumulators exactly as in
 //          xbit_gemv_mfma.h (one returning atomic per element and workgroup; the last arriver converts, stores and clears)
@@ -138,27 +145,36 @@ struct DynParams {
 //          next one, and are permuted into the wave's own 2-4 KB of LDS when the next unit starts; by then they are the
 //          oldest loads in flight, so the wait costs nothing the unit's first rows would not have cost anyway.  No
 //          workgroup barrier besides the one behind the scale table.
-template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1>
+//   MULTI  fused launch: the grid covers the column tiles of up to kMaxMulti weight sets that share K, the bit-width, the group size
+//          and the activation (q / k / v, gate / up); a workgroup looks its set up from its tile number (`sets`, passed by value)
+//          and then runs exactly the code of the plain build on that set's tensors.
+template <int BITS, int UB, int CPL, int NL, int NW, bool NT, int SI, int STW, int LA, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1, bool MULTI = false>
 __global__ void __launch_bounds__(64 * NW)
     gemv_dyn_kernel(const uint32_t* qweight, uint32_t n, uint32_t tiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales,
                     const uint32_t* qzeros, uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t m, uint32_t tab_groups, uint32_t gshift,
-                    uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, const int32_t* g_idx, uint64_t* trace) {
+                    uint32_t act_bytes, uint32_t splits, uint32_t ups, unsigned long long* split_acc, const int32_t* g_idx, uint64_t* trace, uint32_t tcols,
+                    const GemvSets sets) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  const DynParams p = {qweight, n, tiles, kw, units, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u};
+  DynParams p = {qweight, n, tiles, kw, units, tcols, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u, nullptr, (uint32_t)MT};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
   constexpr int CN = NL * CPL;  // columns per workgroup
-  constexpr int HS = 16 / NL;   // NL = 8: the two k-slot parities land in different rows / column slots of D
+  constexpr int HS = NL >= 16 ? 1 : 16 / NL;  // NL = 8: the two k-slot parities land in different rows / column slots of D
+  constexpr bool WIDE = NL == 32;  // 32 lanes side by side (512 contiguous bytes per packed row and instruction at CPL = 4): the two 16-lane column
+                                   // sets share the MFMA's column slots in k-octets of different parity; row block rb of the A operand carries
+                                   // zeros in the other set's octets, so D[8 * rb + m][slot] sums column set rb only (as in xbit_gemv_mfma.h)
   constexpr bool STAMP = (FLAGS & 2) != 0;
   constexpr int ST = 64 * STW;  // staging threads
   constexpr int CHK = Unpack<BITS>::kChunkK;  // k per activation chunk (the span inside which the unpacker pairs fields)
   constexpr int CPT = CHK / 8;                // 16-byte loads per chunk
   constexpr uint32_t kOob = 0x80000000u;
-  static_assert(NL == 16 || NL == 8, "lanes along N");
+  static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
+  static_assert(!WIDE || (MT <= 4 && !GIDX), "128-column tiles: up to four rows, contiguous groups");
   static_assert(STW >= 1 && STW <= NW, "staging waves");
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
+  static_assert(!MULTI || (!GIDX && !SPLIT && FLAGS == 0), "fused launches: contiguous groups, whole K");
   static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
   static_assert(!WAVEACT || (NL == 16 && FLAGS == 0), "8 / 16 / 32 rows: tiles of 16 lanes");
@@ -166,6 +182,7 @@ __global__ void __launch_bounds__(64 * NW)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
   //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * MT * CN floats][bad flags: 8 dwords]
+  //      [128-column tiles: zero activations, UB * 16 * MT dwords]
   uint32_t* const s_act = s_dyn;
   uint32_t* const s_gid = s_act + p.act_bytes / 4u;
   const uint32_t id_dwords = GIDX ? p.ups * (uint32_t)((64 / NL) * UB * 16) : 0u;  // ids: 2 B per k of the range, whatever MT
@@ -173,20 +190,32 @@ __global__ void __launch_bounds__(64 * NW)
   uint32_t* const s_tab_plain = s_tab + (GIDX ? p.tab_groups * (uint32_t)(NL * 4) : 0u);
   float* const s_red = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
   uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * MT * CN + 3) & ~3));
+  uint32_t* const s_zero = s_bad + 8;  // 128-column tiles only: one unit's worth of zero activations (UB * 16 * MT dwords)
 
   const int tid = threadIdx.x, lane = tid & 63, kl = lane / NL, nl = lane % NL;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: unit numbers ride in scalar offsets
   uint64_t stamp[7] = {0, 0, 0, 0, 0, 0, 0};
   if constexpr (STAMP) stamp[0] = __builtin_amdgcn_s_memrealtime();
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
-  const uint32_t tile = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);
+  const uint32_t gtile = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);  // tile of the whole grid
+  uint32_t tile = gtile;  // ... of this workgroup's weight set
+  if constexpr (MULTI) {
+    const uint32_t j = (gtile >= sets.tile_end[0] ? 1u : 0u) + (gtile >= sets.tile_end[1] ? 1u : 0u) + (gtile >= sets.tile_end[2] ? 1u : 0u);
+    tile = gtile - (j ? sets.tile_end[j - 1] : 0u);
+    p.n = sets.n[j];
+    p.zw = sets.zw[j];
+    p.qweight = sets.qweight[j];
+    p.scales = sets.scales[j];
+    p.qzeros = sets.qzeros[j];
+    p.out = sets.out[j];
+  }
   // this workgroup's units [ubeg, uend) and the first activation chunk / group that its LDS images start at
   const uint32_t ubeg = SPLIT ? split * p.ups : 0u;
   const uint32_t uend = SPLIT ? (ubeg + p.ups < p.units ? ubeg + p.ups : p.units) : p.units;
   const uint32_t cbase = ubeg * (uint32_t)(LK * UB * (32 / CHK)), gbase = (ubeg * (uint32_t)LK) >> p.gshift;
   const uint32_t row_bytes = p.n * 4u;
-  const uint32_t col = tile * CN + (uint32_t)(CPL * nl);
-  const bool col_ok = col < p.n;
+  const uint32_t col = tile * p.tcols + (uint32_t)(CPL * nl);
+  const bool col_ok = (uint32_t)(CPL * nl) < p.tcols && col < p.n;
   const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
   const rsrc_t r_a = make_rsrc(p.a, (p.m * p.k * 2u + 3u) & ~3u);  // odd k: the last element's dword must be in range (its other half is masked below)
   const rsrc_t r_s = make_rsrc(p.scales, p.groups * p.n * 2u);
@@ -204,7 +233,7 @@ __global__ void __launch_bounds__(64 * NW)
   // table entry e = (group gbase + e / NL, lane slot e % NL): its scale word(s) and zero-point word(s)
   auto tab_load = [&](uint32_t e, uint32_t(&sr)[2], uint32_t(&zr)[2]) {
     const uint32_t g = gbase + e / NL, snl = e % NL;
-    const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
+    const uint32_t scol = tile * p.tcols + (uint32_t)CPL * snl;
     const uint32_t h0 = g * p.n + scol;  // first scale (half index)
     if constexpr (CPL == 2) {
       sr[0] = __builtin_amdgcn_raw_buffer_load_b32(r_s, h0 * 2u, 0, 0);  // n and col even
@@ -225,7 +254,17 @@ __global__ void __launch_bounds__(64 * NW)
       zr[1] = v.y;
     }
   };
-  if (stager) {
+  constexpr bool NO_SMALL = (FLAGS & 4) != 0, NO_SUM = (FLAGS & 8) != 0, NO_MATH = (FLAGS & 16) != 0;  // lab ablations (see FLAGS)
+  if constexpr (NO_SMALL) {
+#pragma unroll
+    for (int r = 0; r < SI; ++r) {
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) act_raw[r][0][q] = u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+      s_raw[r][0] = s_raw[r][1] = 0x20002000u;
+      z_raw[r][0] = z_raw[r][1] = 0x12345678u + (uint32_t)tid;
+    }
+  }
+  if (stager && !NO_SMALL) {
     if constexpr (GIDX) {
       if (p.g_idx != nullptr) {  // uniform
 #pragma unroll
@@ -387,7 +426,7 @@ __global__ void __launch_bounds__(64 * NW)
     }
     auto tab_store = [&](uint32_t e, const uint32_t(&sr)[2], const uint32_t(&zr)[2]) {
       const uint32_t g = gbase + e / NL, snl = e % NL;
-      const uint32_t scol = tile * CN + (uint32_t)CPL * snl;
+      const uint32_t scol = tile * p.tcols + (uint32_t)CPL * snl;
       uint32_t sb[CPL];
       if constexpr (CPL == 2) {
         sb[0] = sr[0] & 0xFFFFu;
@@ -469,6 +508,9 @@ __global__ void __launch_bounds__(64 * NW)
       }
     }
   }
+  if constexpr (WIDE) {
+    for (int i = tid; i < UB * 16 * MT; i += 64 * NW) s_zero[i] = 0u;
+  }
   {
     const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
     if (lane < 8 && (lane == wv || (wv == 0 && lane >= NW))) s_bad[lane] = (lane == wv && wave_bad) ? 1u : 0u;  // wave 0 also clears the unused slots
@@ -488,7 +530,9 @@ __global__ void __launch_bounds__(64 * NW)
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   // dwords: this lane's k-blocks of the unit (4 octets each, MT rows of 4 dwords per octet), its row of the A operand
   constexpr int OSTEP = MT >= 8 ? (MT + 1) * 4 : MT * 4;  // dwords from one octet to the next (8 / 16 rows: padded, see OST)
-  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(4 * OSTEP) + (uint32_t)(nl % (MT > 16 ? 16 : MT)) * 4u;
+  const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(4 * OSTEP) + (uint32_t)((WIDE ? (nl & 7) : nl) % (MT > 16 ? 16 : MT)) * 4u;
+  // 128-column tiles: a lane whose row block belongs to the OTHER column set feeds zeros (a unit's worth of them sits behind the reduction scratch)
+  const bool zero_lane = WIDE && (nl >> 4) != ((nl >> 3) & 1);
 
   // per-unit dequant constants of this lane's columns
   auto unit_consts = [&](uint32_t u, half2_t(&s2)[CPL], half2_t(&nzs2)[CPL], half2_t(&ss2)[CPL]) {
@@ -509,6 +553,17 @@ __global__ void __launch_bounds__(64 * NW)
                   const half2_t(&ss2)[CPL], const uint32_t(&gq)[GIDX ? UB : 1][16]) {
     constexpr int s = decltype(s_c)::value, j = s / 4, oct = s % 4;
     constexpr bool FAST = decltype(fast_c)::value;
+    if constexpr (NO_MATH) {  // lab ablation: wait for the rows this step reads, compute nothing
+      static_for<(P::need(s) - (s == 0 ? 0 : P::need(s - 1)))>([&](auto d) {
+        constexpr int row = (s == 0 ? 0 : P::need(s - 1)) + decltype(d)::value;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const uint32_t t = X[row].v[c];
+          asm volatile("" ::"v"(t));
+        }
+      });
+      return;
+    }
     const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OSTEP);
     const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
     uint32_t wc[CPL][BITS];
@@ -579,7 +634,7 @@ __global__ void __launch_bounds__(64 * NW)
   auto process = [&](Row<CPL, NT>(&X)[R], Row<CPL, NT>(&Y)[R]) {
     const bool live = cur < uend;  // wave-uniform
     half2_t s2[CPL], nzs2[CPL], ss2[CPL];
-    const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
+    const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : (zero_lane ? s_zero : s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane);
     uint32_t gq[GIDX ? UB : 1][16];
     if constexpr (WAVEACT) {
       if (live) wact_store();  // this unit's activations: requested one unit ago, the oldest loads in flight
@@ -626,7 +681,7 @@ __global__ void __launch_bounds__(64 * NW)
         wact_issue(u);
         wact_store();
       }
-      const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : s_act + (u - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane;
+      const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : (zero_lane ? s_zero : s_act + (u - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane);
       static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2, gq); });
     }
   }
@@ -638,9 +693,19 @@ __global__ void __launch_bounds__(64 * NW)
   // ---- cross-wave sum.  D[row][slot]: row 4 * (lane >> 4) + r lives in register r of lane (lane >> 4, slot = lane & 15).
   // NL = 16: rows 0..MT-1 (registers 0..MT-1 of lanes 0-15) are the sums over the wave's four k-slots for column slot = nl.
   // NL = 8: even k-slots sum into D[m][0..7] (lanes 0-7), odd ones into D[8 + m][8..15] (lanes 40-47). ----
+  if constexpr (NO_SUM) {  // lab ablation: every wave stores its own partial sums, no LDS, no barrier
+    if (lane < 16 && col_ok) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if (col + (uint32_t)c < p.n) p.out[col + (uint32_t)c] = as_u16((_Float16)acc[c][0]);
+    }
+    return;
+  }
   {
-    const int h = NL == 16 ? 0 : (lane >= 32 ? 1 : 0);
-    const bool holder = NL == 16 ? lane < 16 : (lane < 8 || (lane >= 40 && lane < 48));
+    // NL = 32: column set 0 in rows 0.. (lanes 0-15), column set 1 in rows 8.. (lanes 32-47)
+    const int h = NL >= 16 ? 0 : (lane >= 32 ? 1 : 0);
+    const bool holder = NL == 16 ? lane < 16 : (NL == 32 ? (lane < 16 || (lane >= 32 && lane < 48)) : (lane < 8 || (lane >= 40 && lane < 48)));
+    const int hcol = NL == 32 ? (lane >= 32 ? 16 : 0) + (lane & 15) : lane % NL;  // lane slot of the holder's columns
     if constexpr (WAVEACT) {  // rows 4 * (lane >> 4) + r, all four lane groups up to MT
       if (4 * (lane >> 4) < MT) {
 #pragma unroll
@@ -659,7 +724,7 @@ __global__ void __launch_bounds__(64 * NW)
 #pragma unroll
         for (int c = 0; c < CPL; ++c)
 #pragma unroll
-          for (int mi = 0; mi < MT; ++mi) s_red[((wv * HS + h) * MT + mi) * CN + (lane % NL) * CPL + c] = acc[c][mi];
+          for (int mi = 0; mi < MT; ++mi) s_red[((wv * HS + h) * MT + mi) * CN + hcol * CPL + c] = acc[c][mi];
       }
     }
   }
@@ -670,8 +735,8 @@ __global__ void __launch_bounds__(64 * NW)
     float sum = 0.f;
 #pragma unroll
     for (int w = 0; w < NW * HS; ++w) sum += s_red[(w * MT + mi) * CN + cc];
-    const uint32_t n_out = tile * CN + (uint32_t)cc;
-    const bool valid = n_out < p.n && (uint32_t)mi < p.m;
+    const uint32_t n_out = tile * p.tcols + (uint32_t)cc;
+    const bool valid = (uint32_t)cc < p.tcols && n_out < p.n && (uint32_t)mi < p.m;
     if constexpr (SPLIT) {
       // One trip to the device coherence point, as in xbit_gemv_mfma.h: the partial sum goes into the element's 64-bit
       // accumulator as a fixed-point integer (2^-28 units, biased positive) by ONE returning atomic whose upper bits count
@@ -679,7 +744,7 @@ __global__ void __launch_bounds__(64 * NW)
       // or NaN); integer addition is associative, so the result does not depend on the arrival order.  The thread that
       // completes the count converts, stores and clears the slot.  Contract: include/xbitops_hip.h (split_k).
       if (valid) {
-        unsigned long long* slot = p.acc + (size_t)tile * (size_t)(MT * CN) + (size_t)e0;
+        unsigned long long* slot = p.acc + (size_t)gtile * (size_t)(MT * CN) + (size_t)e0;
         const bool fin = __builtin_fabsf(sum) < 524288.0f;
         const long long v = fin ? (long long)__builtin_rintf(sum * 268435456.0f) : 0ll;
         const unsigned long long pos = (!fin && !(sum < 0.f)) ? (1ull << 56) : 0ull;
@@ -716,10 +781,10 @@ __global__ void __launch_bounds__(64 * NW)
 
 // LDS bytes of one workgroup (dynamic)
 inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl, int mt) {
-  const int hs = 16 / nl, cn = nl * cpl;
+  const int hs = nl >= 16 ? 1 : 16 / nl, cn = nl * cpl;
   // act-order: group ids (2 B per k) beside the activations and a second table for the spliced form
   const size_t ids = p.by_id ? (size_t)p.id_bytes : 0u, tables = p.by_id ? 2u : 1u;
-  return (size_t)p.act_bytes + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u + 32u;
+  return (size_t)p.act_bytes + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u + 32u + (nl == 32 ? (size_t)(2 * 16 * mt * 4) : 0u);
 }
 
 constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
@@ -732,15 +797,55 @@ constexpr int dyn_ub() {
   return BITS == 2 ? 2 : 1;  // >= 3 row loads per unit
 }
 
-template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1>
+// NW waves per workgroup, the older half of them staging (8 / 4 everywhere but the 128-column tiles, which run 16 / 8: one workgroup per CU there)
+template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1, int NW = kDynWaves, bool MULTI = false>
 int launch_dyn_one(const DynParams& p, hipStream_t stream) {
   constexpr int UB = dyn_ub<BITS>();
-  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, kDynWaves, NT, SI, kDynStagers, kDynLookahead, FLAGS, SPLIT, GIDX, MT>;
+  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, NW, NT, SI, NW / 2, kDynLookahead, FLAGS, SPLIT, GIDX, MT, MULTI>;
+  static_assert(kDynStagers == kDynWaves / 2, "the older half stages");
   DynParams q = p;
+  GemvSets sets = {};
+  if (MULTI && p.sets != nullptr) sets = *p.sets;
   void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias, &q.m,
-                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.g_idx, &q.trace};
-  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u)), dim3(64 * kDynWaves),
-                            dyn_lds_bytes(p, NL, kDynWaves, CPL, MT), stream, args);
+                  &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.g_idx, &q.trace, &q.tcols, &sets};
+  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u)), dim3(64 * NW),
+                            dyn_lds_bytes(p, NL, NW, CPL, MT), stream, args);
+}
+
+// 128-column tiles (32 lanes x 16 B): 4- and 8-bit, one or up to four rows, whole K, sixteen waves
+constexpr int kDynWideWaves = 16;
+template <int BITS, bool NT>
+int launch_dyn_wide(const DynParams& p, hipStream_t stream, uint32_t rounds) {
+  if constexpr (BITS == 4 || BITS == 8) {
+    if (p.by_id || p.splits > 1u || p.mt > 4u) return kDynNotEligible;
+    if (p.mt > 1u) {
+      if (rounds <= 2u) return launch_dyn_one<BITS, 4, 32, NT, 2, 0, false, false, 4, kDynWideWaves>(p, stream);
+      if (rounds <= 4u) return launch_dyn_one<BITS, 4, 32, NT, 4, 0, false, false, 4, kDynWideWaves>(p, stream);
+      return kDynNotEligible;
+    }
+    if (rounds <= 2u) return launch_dyn_one<BITS, 4, 32, NT, 2, 0, false, false, 1, kDynWideWaves>(p, stream);
+    if (rounds <= 4u) return launch_dyn_one<BITS, 4, 32, NT, 4, 0, false, false, 1, kDynWideWaves>(p, stream);
+    if (rounds <= 8u) return launch_dyn_one<BITS, 4, 32, NT, 8, 0, false, false, 1, kDynWideWaves>(p, stream);
+  }
+  return kDynNotEligible;
+}
+
+// fused launches (p.sets): tiles of 16 lanes, 1..16 rows, whole K
+template <int BITS, int CPL>
+int launch_dyn_multi_si(const DynParams& p, hipStream_t stream, uint32_t rounds) {
+  constexpr int W = kDynWaves;
+  if (p.mt > 8u) return launch_dyn_one<BITS, CPL, 16, true, 2, 0, false, false, 16, W, true>(p, stream);  // table rounds beyond 2: staged in a loop
+  if (p.mt > 4u) return launch_dyn_one<BITS, CPL, 16, true, 2, 0, false, false, 8, W, true>(p, stream);
+  if (p.mt > 1u) {
+    if (rounds <= 2u) return launch_dyn_one<BITS, CPL, 16, true, 2, 0, false, false, 4, W, true>(p, stream);
+    if (rounds <= 4u) return launch_dyn_one<BITS, CPL, 16, true, 4, 0, false, false, 4, W, true>(p, stream);
+    return kDynNotEligible;
+  }
+  if (rounds <= 2u) return launch_dyn_one<BITS, CPL, 16, true, 2, 0, false, false, 1, W, true>(p, stream);
+  if (rounds <= 3u) return launch_dyn_one<BITS, CPL, 16, true, 3, 0, false, false, 1, W, true>(p, stream);
+  if (rounds <= 4u) return launch_dyn_one<BITS, CPL, 16, true, 4, 0, false, false, 1, W, true>(p, stream);
+  if (rounds <= 8u) return launch_dyn_one<BITS, CPL, 16, true, 8, 0, false, false, 1, W, true>(p, stream);
+  return kDynNotEligible;
 }
 
 template <int BITS, int CPL, int NL, bool NT>
@@ -755,10 +860,10 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #endif
   if (p.by_id) {  // act-order: 48-column tiles; 1 or up to 4 rows: K up to 4096 (2 rounds) or 8192 (4 rounds); 5..16 rows: any K
     if constexpr (NL == 16 && CPL == 3) {
-      if (p.m > 16u) return kDynNotEligible;
-      if (p.m > 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 16>(p, stream);
-      if (p.m > 4u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 8>(p, stream);
-      if (p.m > 1u) {
+      if (p.mt > 16u) return kDynNotEligible;
+      if (p.mt > 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 16>(p, stream);
+      if (p.mt > 4u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 8>(p, stream);
+      if (p.mt > 1u) {
         if (rounds <= 2u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 4>(p, stream);
         if (rounds <= 4u) return launch_dyn_one<BITS, CPL, NL, NT, 4, 0, false, true, 4>(p, stream);
         return kDynNotEligible;
@@ -768,22 +873,22 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
     }
     return kDynNotEligible;
   }
-  if (p.m > 4u) {  // 5..16 rows: the per-wave activation pipeline (8- and 16-row builds); the rounds stage the table only
+  if (p.mt > 4u) {  // 5..16 rows (or fewer rows of a K beyond the 1- / 4-row builds' staging rounds): the per-wave activation pipeline (8- and 16-row builds); the rounds stage the table only
     if constexpr (NL == 16) {
       if (p.splits > 1u) {  // split-K (few-column long-K layers: down-projections at small batch), 64-column tiles
         if constexpr (CPL == 4) {
-          if (p.m <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 8>(p, stream);
-          if (p.m <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 16>(p, stream);
+          if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 8>(p, stream);
+          if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 16>(p, stream);
         }
         return kDynNotEligible;
       }
-      if (p.m <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
-      if (p.m <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
+      if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
+      if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
       return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
     }
     return kDynNotEligible;
   }
-  if (p.m > 1u) {  // 2..4 rows: whole-K tiles of 16 lanes, K up to 4096 (2 rounds) or 8192 (4 rounds)
+  if (p.mt > 1u) {  // 2..4 rows: whole-K tiles of 16 lanes, K up to 4096 (2 rounds) or 8192 (4 rounds)
     if constexpr (NL == 16) {
       if (p.splits > 1u) {
         if constexpr (CPL == 4) {
@@ -820,10 +925,14 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 // `splits` >= 2 with `acc` (zeroed accumulators, one per output element of whole tiles): K is cut into that many ranges.
 template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
-                    unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr) {
+                    unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr, uint32_t tcols = 0, const GemvSets* sets = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
   if (g.m < 1u || g.m > 32u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
   if (g.m > 4u && nl != 16) return kDynNotEligible;                              // 5..32 rows: tiles of 16 lanes
+  if (sets != nullptr && (nl != 16 || (cpl != 3 && cpl != 4) || g.m > 16u || g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || stamped || tcols != 0u ||
+                          sets->count < 1u || sets->count > (uint32_t)kMaxMulti))
+    return kDynNotEligible;  // fused launches: 48- or 64-column tiles, whole K, contiguous groups
+  if (nl == 32 && (cpl != 4 || g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || stamped)) return kDynNotEligible;  // 128-column tiles: 16-byte lanes, whole K
   if (g.m > 16u && splits > 1u) return kDynNotEligible;                          // 17..32 rows keep K whole
   if (g.m > 16u && (g_idx != nullptr || g.groupsize % 32u != 0u)) return kDynNotEligible;  // 17..32 rows: contiguous groups
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
@@ -841,7 +950,11 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   }
   if (((uintptr_t)g.a | (uintptr_t)g.qweight | (uintptr_t)g.scales | (uintptr_t)g.qzeros) % 4u != 0u) return kDynNotEligible;  // dword buffer loads
   const uint32_t d = by_id ? 1u : dq;
-  if (nl != 16 && !(nl == 8 && cpl == 2)) return kDynNotEligible;
+  if (nl != 16 && !(nl == 8 && cpl == 2) && !(nl == 32 && cpl == 4)) return kDynNotEligible;
+  // columns a tile owns: the whole lane map unless the caller narrows it (a multiple of cpl: every lane is all in or all out)
+  const uint32_t cn = (uint32_t)(nl * cpl);
+  if (tcols == 0u) tcols = cn;
+  if (tcols > cn || tcols % (uint32_t)cpl != 0u || (by_id && tcols != cn)) return kDynNotEligible;
   DynParams p;
   p.qweight = g.qweight;
   p.n = g.n;
@@ -862,36 +975,69 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   while ((1u << p.gshift) < d) ++p.gshift;
   if (by_id) p.gshift = g.groupsize;  // read only when g_idx is null: the size of the contiguous groups
   const uint32_t lk = 64u / (uint32_t)nl, kblocks = (g.k + 31u) / 32u;
-  p.tiles = (g.n + (uint32_t)(nl * cpl) - 1u) / (uint32_t)(nl * cpl);
+  p.tcols = tcols;
+  p.tiles = (g.n + tcols - 1u) / tcols;
+  p.sets = nullptr;
+  GemvSets fused;
+  if (sets != nullptr) {  // the grid: every set's tiles, one after the other
+    fused = *sets;
+    uint32_t end = 0;
+    for (uint32_t j = 0; j < (uint32_t)kMaxMulti; ++j) {
+      if (j < fused.count) {
+        if (((uintptr_t)fused.qweight[j] | (uintptr_t)fused.scales[j] | (uintptr_t)fused.qzeros[j]) % 4u != 0u || fused.n[j] == 0u || fused.n[j] > g.n) return kDynNotEligible;
+        end += (fused.n[j] + tcols - 1u) / tcols;
+      }
+      fused.tile_end[j] = j < fused.count ? end : 0xFFFFFFFFu;
+    }
+    p.tiles = end;
+    p.sets = &fused;
+  }
   p.units = (kblocks + lk * UB - 1u) / (lk * UB);
   p.splits = splits >= 2u && acc != nullptr ? splits : 1u;
   p.ups = (p.units + p.splits - 1u) / p.splits;
   p.acc = acc;
   if (p.splits > 1u && (p.ups < 8u || (p.splits - 1u) * p.ups >= p.units)) return kDynNotEligible;  // every range holds a unit for every wave
-  const uint32_t mt = g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u)));
-  p.act_bytes = p.ups * lk * UB * 64u * mt;
-  if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
-  p.id_bytes = by_id ? p.ups * lk * UB * 64u : 0u;
-  // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
-  // launches cover at least `groups` rows so that the zero rows past the last group exist
-  p.tab_groups = ((p.ups * lk - 1u + ((1u << p.gshift) - 1u)) >> p.gshift) + 1u;
-  if (p.splits == 1u) {
-    p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
-    if (p.tab_groups < p.groups) p.tab_groups = p.groups;
+  // rows of the build.  The 1- and 4-row builds stage the whole K range of every row up front, a fixed number of rounds per
+  // build (act-order: 4 = K 8192; contiguous: 8 / 4); a longer K takes the 8-row build instead, whose waves fetch their
+  // activations unit by unit and whose table is staged in a loop - rows beyond m read zeros.  (Round 3 fell to the
+  // round-2 kernels there: an act-order down-projection with K = 11008 at batch 1.)
+  uint32_t mt = g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u)));
+  const int waves = nl == 32 ? kDynWideWaves : kDynWaves;
+  const uint32_t st = 64u * (uint32_t)(waves / 2);  // staging threads
+  uint32_t rounds = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    p.mt = mt;
+    p.act_bytes = p.ups * lk * UB * 64u * mt;
+    if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
+    p.id_bytes = by_id ? p.ups * lk * UB * 64u : 0u;
+    // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
+    // launches cover at least `groups` rows so that the zero rows past the last group exist
+    p.tab_groups = ((p.ups * lk - 1u + ((1u << p.gshift) - 1u)) >> p.gshift) + 1u;
+    if (p.splits == 1u) {
+      p.tab_groups = ((p.units * lk - 1u) >> p.gshift) + 1u;
+      if (p.tab_groups < p.groups) p.tab_groups = p.groups;
+    }
+    if (by_id) p.tab_groups = p.groups;  // every group, whatever K
+    const uint32_t chunks = mt >= 8u ? 0u : p.act_bytes / mt / (uint32_t)(Unpack<BITS>::kChunkK * 2);  // a staging thread takes one chunk of every row per round
+    const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
+    const uint32_t r_gid = by_id && mt < 8u ? (p.id_bytes / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round (8 / 16 rows: beyond 2 rounds in a loop)
+    const uint32_t r_tab_static = by_id ? 0u : r_tab;  // the by-id build stages table entries beyond its static rounds in a loop
+    rounds = r_act > r_tab_static ? (r_act > r_gid ? r_act : r_gid) : (r_tab_static > r_gid ? r_tab_static : r_gid);
+    const uint32_t max_rounds = (by_id || mt == 4u || p.splits > 1u) ? 4u : 8u;
+    if (attempt == 0 && mt < 8u && rounds > max_rounds && nl == 16 && !stamped && (by_id || mt == 4u) && (p.splits == 1u || cpl == 4)) {
+      mt = 8u;  // 8-row build: any K
+      continue;
+    }
+    break;
   }
-  if (by_id) p.tab_groups = p.groups;  // every group, whatever K
-  if (dyn_lds_bytes(p, nl, kDynWaves, cpl, (int)mt) > (by_id || mt == 32u ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
+  if (dyn_lds_bytes(p, nl, waves, cpl, (int)mt) > (by_id || mt == 32u || nl == 32 ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
   if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
-  constexpr uint32_t st = 64u * kDynStagers;
-  const uint32_t chunks = mt >= 8u ? 0u : p.act_bytes / mt / (uint32_t)(Unpack<BITS>::kChunkK * 2);  // a staging thread takes one chunk of every row per round
-  const uint32_t r_act = (chunks + st - 1u) / st, r_tab = (p.tab_groups * (uint32_t)nl + st - 1u) / st;
-  const uint32_t r_gid = by_id && mt < 8u ? (p.id_bytes / 16u + st - 1u) / st : 0u;  // 8 ids per staging thread and round (8 / 16 rows: beyond 2 rounds in a loop)
-  const uint32_t r_tab_static = by_id ? 0u : r_tab;  // the by-id build stages table entries beyond its static rounds in a loop
-  const uint32_t rounds = r_act > r_tab_static ? (r_act > r_gid ? r_act : r_gid) : (r_tab_static > r_gid ? r_tab_static : r_gid);
+  if (sets != nullptr) return cpl == 4 ? launch_dyn_multi_si<BITS, 4>(p, stream, rounds) : launch_dyn_multi_si<BITS, 3>(p, stream, rounds);
 #define XBIT_DYN(CPL_, NL_)                                                                      \
   return nt ? launch_dyn_si<BITS, CPL_, NL_, true>(p, stream, rounds, stamped)                   \
             : launch_dyn_si<BITS, CPL_, NL_, XBIT_TUNING ? false : true>(p, stream, rounds, stamped)
+  if (nl == 32) return nt ? launch_dyn_wide<BITS, true>(p, stream, rounds) : launch_dyn_wide<BITS, XBIT_TUNING ? false : true>(p, stream, rounds);
   if (nl == 8) { XBIT_DYN(2, 8); }
   if (cpl == 4) { XBIT_DYN(4, 16); }
   if (cpl == 3) { XBIT_DYN(3, 16); }

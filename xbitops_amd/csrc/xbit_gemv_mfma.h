@@ -876,7 +876,14 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
       return kGemvDynNotEligible;  // the 16-column tiles take one row; 2-4 rows pay at 4 and 8 bits only (rule below)
     int dcpl = auto_small_n ? 2 : auto_cpl, dnl = auto_small_n ? 8 : 16;
     bool nt = true, stamped = false;
+    uint32_t tcols = 0;
 #if XBIT_TUNING
+    if (variant >= 340 && variant <= 343) {  // round 4: 128-column tiles of the staged-operand kernel (340), tiles narrowed so that their count fills the chip (341: 128-column lane map, 342 / 343: 64 / 48)
+      dcpl = variant == 343 ? 3 : 4;
+      dnl = variant <= 341 ? 32 : 16;
+      if (variant != 340) tcols = fill_tcols(p.n, (uint32_t)(dnl * dcpl), (uint32_t)dcpl);
+      return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, true, false, nullptr, 1, nullptr, nullptr, tcols);
+    }
     if (variant == 399 || variant == 398 || (variant > 0 && (variant < 300 || variant > 320))) return kGemvDynNotEligible;
     if (variant >= 310 && variant <= 314) nt = false;
     const int v = variant >= 310 && variant <= 314 ? variant - 10 : variant;
@@ -884,7 +891,7 @@ int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& o
     if (v >= 302 && v <= 304) dcpl = v - 300, dnl = 16;
     if (variant == 320) stamped = true;
 #endif
-    return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, nt, stamped, opts.trace);
+    return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, nt, stamped, opts.trace, 1, nullptr, nullptr, tcols);
   };
   // ---- split-K plan for one row on few-column, long-K layers (called from the group-size branches below) ----
   // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).

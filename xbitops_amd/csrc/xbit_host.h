@@ -54,6 +54,18 @@ struct GemvMultiParams : GemvParams {
   uint16_t* multi_out[kMaxMulti];
 };
 
+// Fused launches of the staged-operand kernel (xbit_gemv_dyn.h, MULTI builds): the weight sets of one launch.  Passed to the
+// kernel by value; tile t of the grid belongs to set j with tile_end[j-1] <= t < tile_end[j] (filled in by the launcher,
+// which knows the tile width; unused entries: tile_end = 0xFFFFFFFF).
+struct GemvSets {
+  uint32_t count;
+  uint32_t tile_end[kMaxMulti], n[kMaxMulti], zw[kMaxMulti];
+  const uint32_t* qweight[kMaxMulti];
+  const uint16_t* scales[kMaxMulti];
+  const uint32_t* qzeros[kMaxMulti];
+  uint16_t* out[kMaxMulti];
+};
+
 // Act-order launches (xbit_gidx.hip): the group of row k is g_idx[k].
 struct GemvGidxParams {
   uint16_t* out;            // fp16 [m, n] (gemv) or [k, n] (dequant)
@@ -97,6 +109,9 @@ struct ProfileState {
   bool series = false;
   int series_used = 0, series_capacity = 0;
   std::vector<hipEvent_t> series_events;  // start, stop, start, stop, ...
+  // dry run (xbit_dry_run_begin / _end): launches are recorded, not issued
+  bool dry_run = false;
+  std::vector<xbit_launch_record> records;
 };
 ProfileState& profile_state();
 
@@ -129,6 +144,15 @@ inline int pick_cpl(uint32_t n) {
   return best;
 }
 
+// Columns a tile should own so that the tile count fills whole rounds of the chip's 256 CUs: the lane map's `cn` columns
+// (cn = lanes x cpl) unless a narrower tile - a multiple of cpl - brings the count up to the next multiple of 256
+// (28672 columns, cn 128: 224 tiles of 128 -> 256 tiles of 112; cn 64: 448 -> 512 tiles of 56).
+inline uint32_t fill_tcols(uint32_t n, uint32_t cn, uint32_t cpl) {
+  const uint32_t tiles = (n + cn - 1u) / cn, target = ((tiles + 255u) / 256u) * 256u;
+  const uint32_t per = (n + target - 1u) / target, t = ((per + cpl - 1u) / cpl) * cpl;
+  return t < cn ? t : cn;
+}
+
 int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
 // act-order dequant on the tile kernel (n % 8 == 0, 16-byte aligned qweight / scales / out, kblocks within the grid limit)
 int launch_dequant_by_id(const DequantParams& p, const int32_t* g_idx, int bits, hipStream_t stream);
@@ -141,7 +165,12 @@ int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
 constexpr int kGemvDynNotEligible = 1 << 30;
 // splits >= 2 with acc (zeroed 64-bit accumulators, one per output element of whole tiles): K cut into that many ranges
 int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
-                    unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr);  // xbit_gemv_dyn.hip; g_idx: act-order (group of row k), 48-column tiles, whole K
+                    unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr,  // xbit_gemv_dyn.hip; g_idx: act-order (group of row k), 48-column tiles, whole K
+                    uint32_t tcols = 0);  // columns a tile owns (0: the whole lane map, nl * cpl); nl = 32: 128-column tiles (4- and 8-bit, up to four rows)
+// Fused launch through the staged-operand kernel: `p` describes the shared operands (a, m, k, group size, bias; n = the widest set),
+// `sets` the weight sets (count, n, zw, pointers; tile_end is filled in here).  1..16 rows, whole K, tiles of 16 * cpl columns
+// (cpl 3 or 4).  kGemvDynNotEligible when the shape is not for that kernel.
+int launch_gemv_dyn_multi(const GemvParams& p, const GemvSets& sets, int bits, hipStream_t stream, int cpl);  // xbit_gemv_dyn.hip
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);     // xbit_gidx.hip
 int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);
 

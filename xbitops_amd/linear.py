@@ -19,10 +19,26 @@ from . import ops, packing
 # 128.  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM), so the fused one keeps
 # the lead up to about 128 rows.
 GEMV_MAX_ROWS = 128
+# ... for layers the multi-row builds take: in_features % 8 == 0 and a group size that is a power-of-two multiple of 32 (64 at
+# 2 bits).  Other layers get 16 rows per launch at best (odd group sizes: the by-id builds) or the column kernel's 4-row passes
+# (ragged K), so beyond 16 rows they go to dequantise + dense GEMM as in round 2.
+GEMV_MAX_ROWS_OTHER = 16
 # General act-order layers (any g_idx): the library takes rows sixteen to a launch (4096x11008 w4: 10.4 us at one row, 11.9
 # at sixteen - profiles/r03/gidx_rows_8_16.txt); three launches (36 us) still beat the act-order dequant (25 us) plus the
 # dense GEMM (23 us and more), four do not.
 GIDX_GEMV_MAX_ROWS = 48
+# ... where the by-id builds take the layer (its table of every group fits in LDS: 512 B per group, about 290 groups); a
+# layer with more groups runs the round-2 act-order kernel, one launch per row - worth it for a decode step only.
+GIDX_GEMV_MAX_ROWS_OTHER = 4
+GIDX_TABLE_MAX_GROUPS = 290
+
+
+def fused_rows_limit(in_features: int, groupsize: int, bits: int) -> int:
+    """Rows up to which a contiguous-group layer of this shape should take the fused kernel rather than dequantise + dense GEMM."""
+    unit = 64 if bits == 2 else 32
+    q = groupsize // unit
+    regular = in_features % 8 == 0 and groupsize % unit == 0 and q >= 1 and (q & (q - 1)) == 0
+    return GEMV_MAX_ROWS if regular else GEMV_MAX_ROWS_OTHER
 
 
 class QuantLinear(torch.nn.Module):
@@ -123,7 +139,7 @@ class QuantLinear(torch.nn.Module):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.in_features).to(torch.float16).contiguous()
         if self.g_idx is not None:  # general act-order: the group of row k is g_idx[k]
-            if x2.shape[0] <= GIDX_GEMV_MAX_ROWS:
+            if x2.shape[0] <= (GIDX_GEMV_MAX_ROWS if self.scales.shape[0] <= GIDX_TABLE_MAX_GROUPS else GIDX_GEMV_MAX_ROWS_OTHER):
                 y = ops.gemv_gidx(x2, self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.in_features, self.add_zero_bias)
             else:
                 y = x2 @ self.dequantize()
@@ -132,7 +148,7 @@ class QuantLinear(torch.nn.Module):
             return y.reshape(*lead, self.out_features)
         if self.perm is not None:  # rows sorted by group at load time: the same sum over k in that order
             x2 = x2.index_select(1, self.perm)
-        if x2.shape[0] <= GEMV_MAX_ROWS:
+        if x2.shape[0] <= fused_rows_limit(self.in_features, self.groupsize, self.bits):
             plan = self._plan
             if plan is None or not plan.matches(self.qweight, self.scales, self.qzeros):
                 plan = self._plan = ops.GemvPlan(self.qweight, self.scales, self.qzeros, self.groupsize, self.bits, self.in_features, self.add_zero_bias)
@@ -144,13 +160,17 @@ class QuantLinear(torch.nn.Module):
         return y.reshape(*lead, self.out_features)
 
 
+FUSED_GROUP_MAX_ROWS = 16  # rows one fused launch takes (xbit_gemv_multi_f16 on the staged-operand kernel)
+
+
 class QuantLinearGroup(torch.nn.Module):
     """Several :class:`QuantLinear` layers that read the SAME input (q/k/v, gate/up).
 
-    ``forward(x)`` returns the list of their outputs.  Up to four rows (a decode step, a short speculative batch) go through
-    ``ops.gemv_multi`` - one kernel launch for the whole group instead of one per layer, which is what
+    ``forward(x)`` returns the list of their outputs.  Up to sixteen rows (a decode step, a speculative or small batch) go
+    through ``ops.gemv_multi`` - one kernel launch for the whole group instead of one per layer, which is what
     the small layers of a decoder need (they sit on the launch floor); anything else runs the layers
-    one by one.  The layers must share ``in_features``, ``bits``, ``groupsize`` and ``add_zero_bias``.
+    one by one.  The layers must share ``in_features``, ``bits``, ``groupsize`` and ``add_zero_bias``; act-order layers
+    (``perm`` / ``g_idx``) are run one by one.
     """
 
     def __init__(self, layers):
@@ -168,7 +188,7 @@ class QuantLinearGroup(torch.nn.Module):
         first = self.layers[0]
         lead = x.shape[:-1]
         x2 = x.reshape(-1, first.in_features)
-        if not 1 <= x2.shape[0] <= 4:  # the fused launch takes up to 4 rows
+        if not 1 <= x2.shape[0] <= FUSED_GROUP_MAX_ROWS or any(layer.perm is not None or layer.g_idx is not None for layer in self.layers):
             return [layer(x) for layer in self.layers]
         x2 = x2.to(torch.float16).contiguous()
         ys = ops.gemv_multi(x2, [(layer.qweight, layer.scales, layer.qzeros) for layer in self.layers], first.groupsize, first.bits,
