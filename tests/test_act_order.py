@@ -103,7 +103,8 @@ def test_act_order_kernels_vs_oracle(bits, cuda_device):
 
     for k, n, g, m, equal in ((4096, 256, 128, 1, True), (1000, 68, 40, 3, False), (8192, 64, 32, 2, True), (4096 + 64, 132, 128, 1, False),
                               (96, 6, 16, 1, False), (4096, 200, 128, 8, False), (8192, 96, 64, 16, True), (2048, 144, 128, 13, False),
-                              (4096, 64, 128, 40, True), (1000, 68, 40, 7, False)):  # 5..16 rows: the 8- / 16-row by-id builds; 40: 16 + 16 + 8
+                              (4096, 64, 128, 40, True), (1000, 68, 40, 7, False),  # 5..16 rows: the 8- / 16-row by-id builds; 40: 32 + 8
+                              (11008, 96, 128, 1, True), (11008, 96, 128, 4, False), (11008, 64, 128, 20, True), (4096, 130, 128, 27, False)):  # K beyond the 1- / 4-row builds' staging: the 8-row build; 17..32 rows: the 32-row build
         p, g_idx = _act_order_problem(k, n, bits, g, m, 100 * bits + n, equal)
         a, qw, sc, qz, gi = _to_dev(cuda_device, p.act, p.qweight, p.scales, p.qzeros, g_idx)
         w = ops.dequant_gidx(qw, sc, qz, gi, bits, k, 1).cpu().numpy()

@@ -324,3 +324,28 @@ def test_fused_launch_every_width_up_to_sixteen_rows(bits, cuda_device):
         for y, ref, n in zip(ys, refs, ns):
             assert y.shape == (m, n)
             _close(y.cpu().numpy(), ref, "fused bits=%d k=%d ns=%s n=%d m=%d" % (bits, k, ns, n, m), k=k)
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_ragged_k_with_several_rows(bits, cuda_device):
+    """A row length that is no multiple of 8 - even or odd - at 2..40 rows: the 4- / 8- / 16- / 32-row builds mask the piece that
+    holds element k - 1 where they stage it (the reference harness's own K = 7167, main.cc:21, at more than one row)."""
+    lib = _lib.load()
+    for k, n, g, m in [(7166, 1024, 128, 4), (4098, 520, 128, 2), (1002, 130, 64, 8), (7166, 4096, 128, 16), (4100, 2048, 128, 24), (2046, 256, 128, 40),
+                       # odd K: every other row begins on an odd halfword and is read unaligned
+                       (7167, 4096, 128, 4), (7167, 512, 128, 16), (4097, 256, 128, 32), (1001, 130, 64, 3), (63, 64, 64, 2), (7167, 1024, 128, 37)]:
+        if bits == 2 and g < 64:
+            continue
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 11 + k + m)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m), k=k)
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_odd_group_sizes_seventeen_to_forty_rows(bits, cuda_device):
+    """17..32 rows of a group size that is no multiple of 32: the 32-row by-id build; more rows: launches of 32."""
+    lib = _lib.load()
+    for k, n, g, m in [(2048, 256, 48, 19), (4096, 1024, 48, 24), (1000, 66, 1000, 33), (4096, 130, 80, 32), (2048, 512, 16, 40)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m), k=k)

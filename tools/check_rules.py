@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Do the launch rules (xbitops_amd/csrc/xbit_gemv_rules.h) still pick the fastest launch?  GPU.
+
+For every point of a held-out list of (bits, rows, K, N, group) - shapes no sweep behind a rule was run on - the automatic launch of the
+PRODUCTION library is timed next to every forced launch the measurement library offers for that point (the staged-operand kernel on each
+tile width, the round-2 kernels with and without their split plans, 128-column tiles, forced split counts).  Clock: the period of a
+dependent chain of launches, cold HBM - what a decoder pays per layer.  The check FAILS (exit 1) when the automatic launch takes more than
+`--slack` (default 1.08) times the best forced one on any point; a kernel or rule edit that silently invalidates a threshold shows up here.
+
+    python tools/check_rules.py [--slack 1.08] [--points all|quick] > profiles/rNN/check_rules.txt
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from xbitops_amd import _lib, synth  # noqa: E402
+import gemv_sweep  # noqa: E402
+
+# (bits, rows, K, N, group): none of these shapes appears in a sweep under profiles/r01..r03 that a rule cites
+POINTS = [
+    # one row, many tiles / few tiles / wide
+    (4, 1, 3072, 9216, 128), (4, 1, 6656, 6656, 128), (4, 1, 8192, 16384, 128), (4, 1, 4096, 22016, 128), (4, 1, 6144, 16384, 128), (4, 1, 5120, 27648, 128),
+    (4, 1, 4096, 1536, 128), (4, 1, 6144, 2048, 128), (4, 1, 2048, 8192, 128), (3, 1, 6656, 6656, 128), (3, 1, 3072, 9216, 128), (3, 1, 8192, 2560, 128),
+    (2, 1, 6144, 16384, 128), (2, 1, 4096, 6144, 128), (5, 1, 3072, 9216, 128), (5, 1, 6144, 4096, 64), (6, 1, 6656, 6656, 128), (7, 1, 4096, 6144, 64),
+    (8, 1, 6144, 16384, 128), (8, 1, 4096, 2048, 128), (8, 1, 4096, 22016, 128),
+    # long K, few columns: split plans
+    (4, 1, 10240, 2560, 128), (4, 1, 22016, 4096, 128), (4, 1, 16384, 3072, 128), (4, 1, 24576, 1536, 128), (3, 1, 10240, 5120, 128), (5, 1, 16384, 3072, 128),
+    (8, 1, 10240, 2560, 128), (2, 1, 22016, 4096, 128), (4, 1, 16384, 7168, 128),
+    # group sizes 64 / 32
+    (4, 1, 6656, 6656, 64), (3, 1, 6144, 16384, 64), (4, 1, 3072, 9216, 32), (8, 1, 6144, 4096, 32),
+    # several rows
+    (4, 2, 3072, 9216, 128), (4, 4, 6144, 16384, 128), (8, 4, 6656, 6656, 128), (3, 4, 6144, 16384, 128), (4, 8, 3072, 9216, 128), (4, 8, 6144, 2048, 128),
+    (5, 8, 6656, 6656, 128), (4, 16, 6144, 16384, 128), (3, 16, 3072, 9216, 128), (4, 16, 22016, 4096, 128), (4, 16, 4096, 1536, 128), (8, 12, 6656, 6656, 128),
+    (4, 32, 3072, 9216, 128), (4, 24, 6144, 16384, 128), (2, 32, 6656, 6656, 128), (4, 32, 6144, 2048, 128), (4, 64, 3072, 9216, 128), (4, 48, 6656, 6656, 128),
+]
+QUICK = POINTS[::4]
+
+
+def candidates(bits, m, k, n, g):
+    """(label, variant, split) of every forced launch that applies to the point; the measurement library falls back to the round-2
+    kernels where a forced launch does not take the shape, so a candidate can only be as slow as those."""
+    kb, t32 = (k + 31) // 32, (n + 31) // 32
+    c = [("round-2 kernels, unsplit", 399, 0), ("round-2 rules (their split plans)", 398, 0), ("staged-operand, automatic tile", 300, 0),
+         ("staged-operand, 32 columns", 302, 0), ("staged-operand, 48 columns", 303, 0), ("staged-operand, 64 columns", 304, 0)]
+    if m == 1:
+        c.append(("staged-operand, 16 columns", 301, 0))
+    if bits in (4, 8) and m <= 4 and n >= 16384:
+        c.append(("staged-operand, 128 columns", 340, 0))
+        if m == 1:
+            c.append(("round-2 kernel, 128 columns", 107, 0))
+    if m == 1 and kb >= 256 and t32 <= 256 and g % 128 == 0:
+        for s in (2, 3, 4, 6, 8, 12):
+            c.append(("staged-operand split x%d, 64 columns" % s, 334, s))
+        for s in (4, 8):
+            c.append(("staged-operand split x%d, 32 columns" % s, 332, s))
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--slack", type=float, default=1.08)
+    ap.add_argument("--points", default="all", choices=("all", "quick"))
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    prod, tun = _lib.load(), _lib.load_tuning()
+    points = POINTS if args.points == "all" else QUICK
+    print("# device %s; period of a dependent chain of launches, cold, us; the automatic launch (production library) against every forced launch; slack %.2f" % (
+        torch.cuda.get_device_name(0), args.slack), flush=True)
+    failed = 0
+    for bits, m, k, n, g in points:
+        iters = 60 if k * n > 5e7 else 120
+
+        def period(lib, variant, split):
+            return gemv_sweep.gemv_case(lib, dev, k, n, bits, g, m, True, iters, variant, split, both=True)[4]
+
+        auto = period(prod, -1, 0)
+        best, best_label, cells = auto, "automatic", []
+        for label, v, s in candidates(bits, m, k, n, g):
+            try:
+                t = period(tun, v, s)
+            except AssertionError:
+                continue
+            cells.append("%s %.2f" % (label, t))
+            if t < best:
+                best, best_label = t, label
+        auto2 = period(prod, -1, 0)  # the automatic launch once more, after the others: the box drifts by a per cent or two over a point
+        auto = min(auto, auto2)
+        ok = auto <= args.slack * best
+        failed += 0 if ok else 1
+        print("%s w%d m%-3d %5dx%-5d g%-3d  automatic %7.2f  best %7.2f (%s)  ratio %.3f" % ("ok  " if ok else "FAIL", bits, m, k, n, g, auto, best, best_label, auto / best), flush=True)
+        print("       " + "; ".join(cells), flush=True)
+    print("# %d of %d points within %.2f x the best forced launch" % (len(points) - failed, len(points), args.slack), flush=True)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

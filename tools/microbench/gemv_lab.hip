@@ -243,6 +243,7 @@ int main(int argc, char** argv) {
   cands.push_back(dyn_candidate<3, 8, true, 4, 12>("ablation: no small loads, no sum", pr, d));
   cands.push_back(dyn_candidate<3, 8, true, 4, 16>("ablation: no unpack / MFMA", pr, d));
   cands.push_back(dyn_candidate<3, 8, true, 4, 28>("ablation: row loads only", pr, d));
+  cands.push_back(dyn_candidate<3, 8, true, 4, 32>("48-col, v_dot2 accumulate instead of the MFMA", pr, d));
   // sixteen waves per workgroup (two units each): twice the rows in flight per CU
   cands.push_back(dyn_candidate<3, 16, true, 4>("48-col, 16 waves, waves 0-3 stage", pr, d));
   cands.push_back(dyn_candidate<3, 16, true, 8>("48-col, 16 waves, waves 0-7 stage", pr, d));

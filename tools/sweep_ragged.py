@@ -23,7 +23,10 @@ CASES = [  # (K, N, group, rows, note)
     (4096, 11008, 128, 1, "aligned neighbour (the metric shape)"),
     (4100, 11008, 128, 1, "K % 32 != 0"),
     (7168, 4096, 128, 4, "aligned neighbour, 4 rows"),
-    (7167, 4096, 128, 4, "ragged K with 4 rows: column kernel"),
+    (7167, 4096, 128, 4, "ragged ODD K with 4 rows (rows begin on odd halfwords)"),
+    (7166, 4096, 128, 4, "ragged even K with 4 rows: 4-row build, masked tail (round 3: column kernel, 85 us)"),
+    (7166, 4096, 128, 16, "ragged even K with 16 rows: 16-row build, masked tail"),
+    (7166, 4096, 128, 32, "ragged even K with 32 rows: 32-row build, masked tail"),
     (4096, 4096, 64, 1, "aligned neighbour, group 64"),
     (4096, 4096, 48, 1, "group 48: by-id build, ids computed"),
     (4096, 4096, 16, 1, "group 16: by-id build (256 groups: 128 KB of table)"),
@@ -31,7 +34,8 @@ CASES = [  # (K, N, group, rows, note)
     (4096, 4096, 48, 4, "group 48, 4 rows: by-id build"),
     (4096, 4096, 48, 8, "group 48, 8 rows: by-id build (8-row)"),
     (4096, 4096, 48, 16, "group 48, 16 rows: by-id build (16-row)"),
-    (4096, 4096, 48, 24, "group 48, 24 rows: column kernel"),
+    (4096, 4096, 48, 24, "group 48, 24 rows: 32-row by-id build (round 3: column kernel, 93 us)"),
+    (4096, 4096, 48, 40, "group 48, 40 rows: launches of 32 + 8"),
 ]
 
 

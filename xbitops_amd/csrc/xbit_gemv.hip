@@ -27,6 +27,7 @@
 //     sum over waves goes through LDS, the result is stored as fp16 (RNE).
 #include "xbit_device.h"
 #include "xbit_host.h"
+#include "xbit_launch_all.h"
 
 namespace xbit {
 
@@ -384,13 +385,29 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
   if (dot2_ok && opts.variant >= 1 && opts.variant < 10) return launch_bits<4>(p, stream, opts.variant);
 #endif
   if (mfma_ok) return launch_gemv_mfma(p, bits, stream, opts);
-  // One row of any length k (the reference harness's own K = 7167, main.cc:21): the staged-operand kernel masks the tail
-  // of the activation vector itself.  Group sizes that are not a multiple of 32 (16, 48, 80 ...; one to sixteen rows): the
-  // same kernel's by-id builds, which look every row's group up (ids computed as k / groupsize).  What is left for the
-  // column kernel below: ragged k with several rows, more than sixteen rows of an odd group size, tensors that are not
-  // 4-byte aligned or reach 2 GiB (profiles/r03/sweep_ragged_shapes.txt).
-  if (p.m <= 16u && (p.m == 1u || p.k % 8u == 0u) && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
-    const int st = launch_gemv_dyn(p, bits, stream, pick_cpl(p.n), 16, true, false, nullptr);
+  // Whatever the round-2 kernel's alignment rules exclude: any row length k (the reference harness's own K = 7167, main.cc:21;
+  // the staged-operand kernel masks the tail where it stages the activations, and reads rows that begin on an odd halfword
+  // unaligned), group sizes that are no multiple of 32 (16, 48, 80 ...: the same kernel's by-id builds, ids computed as
+  // k / groupsize), activations and scales on any halfword - up to 128 rows.  What is left for the column kernel below: more rows
+  // than that, tensors of 2 GiB and more, staged operands beyond LDS (profiles/r04/sweep_ragged_shapes.txt).
+  if (p.m <= 128u && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
+    // rows in launches of up to 32 (each streams the weights once more) - of 16 where the 32-row build does not take the layer;
+    // every chunk is checked before the first goes out
+    GemvParams q = p;
+    int st = kGemvDynNotEligible;
+    for (uint32_t chunk = 32u; chunk >= 16u && st == kGemvDynNotEligible; chunk /= 2u) {
+      st = launch_all_or_nothing([&]() -> int {
+        int s = kGemvDynNotEligible;
+        for (uint32_t r0 = 0; r0 < p.m; r0 += chunk) {
+          q.m = p.m - r0 < chunk ? p.m - r0 : chunk;
+          q.a = p.a + (size_t)r0 * p.k;
+          q.out = p.out + (size_t)r0 * p.n;
+          s = launch_gemv_dyn(q, bits, stream, pick_cpl(p.n), 16, true, false, nullptr);
+          if (s != XBIT_OK) break;
+        }
+        return s;
+      });
+    }
     if (st != kGemvDynNotEligible) return st;
   }
   // everything else: exact, coalesced, a few times slower than the fast kernels

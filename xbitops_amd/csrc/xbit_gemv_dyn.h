@@ -112,6 +112,7 @@ struct DynParams {
   uint32_t id_bytes;        // host side only: LDS bytes of the staged group ids (2 B per k of the range), 0 without by_id
   const GemvSets* sets;     // host side only: the weight sets of a fused launch (MULTI builds), else null
   uint32_t mt;              // host side only: rows of the build that takes this launch (1, 4, 8, 16, 32; >= m)
+  uint32_t wide_probe;      // host side only, tuning builds: which measurement build of the 128-column tiles (0: the production one)
 };
 
 // Template parameters
@@ -127,7 +128,9 @@ struct DynParams {
 //   FLAGS  2 = per-wave stamps to p.trace (measurement builds).  Ablations, compiled by tools/microbench/gemv_lab.hip ONLY (they do
 //          not compute the GEMV; the library never instantiates them): 4 = the staging waves load no small operand (constants go
 //          through the same staging code), 8 = no cross-wave sum (every wave stores its own partial sums), 16 = no unpack / MFMA
-//          (the rows are loaded and waited for, nothing is computed)
+//          (the rows are loaded and waited for, nothing is computed).  32 = (MT = 1, NL = 16; tuning library, results equal) the
+//          multiply-accumulate on the VALU - v_dot2_f32_f16 per weight pair, the four k-slots of a column summed by two
+//          __shfl_xor at the end - instead of the MFMA: the north star's "no MFMA" design, for the A/B of DESIGN.md section 3
 //   SPLIT  split-K: workgroup (tile, split) sums units [split * ups, (split + 1) * ups) only and stages only that range's
 //          activations and groups; the partial sums meet in per-element 64-bit fixed-point accumulators exactly as in
 //          xbit_gemv_mfma.h (one returning atomic per element and workgroup; the last arriver converts, stores and clears)
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(64 * NW)
                     const GemvSets sets) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  DynParams p = {qweight, n, tiles, kw, units, tcols, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u, nullptr, (uint32_t)MT};
+  DynParams p = {qweight, n, tiles, kw, units, tcols, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u, nullptr, (uint32_t)MT, 0u};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
@@ -188,8 +191,12 @@ __global__ void __launch_bounds__(64 * NW)
   const uint32_t id_dwords = GIDX ? p.ups * (uint32_t)((64 / NL) * UB * 16) : 0u;  // ids: 2 B per k of the range, whatever MT
   uint32_t* const s_tab = s_gid + id_dwords;
   uint32_t* const s_tab_plain = s_tab + (GIDX ? p.tab_groups * (uint32_t)(NL * 4) : 0u);
-  float* const s_red = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
-  uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red + ((NW * HS * MT * CN + 3) & ~3));
+  // 32 rows: the reduction scratch (NW * 32 * CN floats: 48-64 KB) REUSES the activation region, which is larger and idle by then - one
+  // more workgroup barrier in front of the epilogue buys the LDS that lets the by-id build take layers with many groups
+  constexpr bool ALIAS = MT == 32;
+  float* const s_red_own = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
+  float* const s_red = ALIAS ? reinterpret_cast<float*>(s_act) : s_red_own;
+  uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red_own + (ALIAS ? 0 : ((NW * HS * MT * CN + 3) & ~3)));
   uint32_t* const s_zero = s_bad + 8;  // 128-column tiles only: one unit's worth of zero activations (UB * 16 * MT dwords)
 
   const int tid = threadIdx.x, lane = tid & 63, kl = lane / NL, nl = lane % NL;
@@ -217,7 +224,11 @@ __global__ void __launch_bounds__(64 * NW)
   const uint32_t col = tile * p.tcols + (uint32_t)(CPL * nl);
   const bool col_ok = (uint32_t)(CPL * nl) < p.tcols && col < p.n;
   const rsrc_t r_w = make_rsrc(p.qweight, p.kw * row_bytes);
-  const rsrc_t r_a = make_rsrc(p.a, (p.m * p.k * 2u + 3u) & ~3u);  // odd k: the last element's dword must be in range (its other half is masked below)
+  // Odd k: the dword that holds the last element must be in range (its other half is masked where it is staged).  With several
+  // rows of odd length every other row begins on an odd halfword; its dwords are read unaligned (the chip serves them:
+  // profiles/r04/unaligned_probe.txt) and the last one of the last row may reach two bytes further - m * k * 2 is then no
+  // multiple of 4096 (m <= 32), so those two bytes lie in the tensor's own last page.
+  const rsrc_t r_a = make_rsrc(p.a, ((p.m * p.k * 2u + 3u) & ~3u) + (((p.k & 1u) != 0u && p.m > 1u) ? 4u : 0u));
   const rsrc_t r_s = make_rsrc(p.scales, p.groups * p.n * 2u);
   const rsrc_t r_z = make_rsrc(p.qzeros, p.groups * p.zw * 4u);
   const bool stager = wv < STW;  // wave-uniform
@@ -255,6 +266,8 @@ __global__ void __launch_bounds__(64 * NW)
     }
   };
   constexpr bool NO_SMALL = (FLAGS & 4) != 0, NO_SUM = (FLAGS & 8) != 0, NO_MATH = (FLAGS & 16) != 0;  // lab ablations (see FLAGS)
+  constexpr bool VALU_ACC = (FLAGS & 32) != 0;  // v_dot2 accumulate instead of the MFMA (measurement build)
+  static_assert(!VALU_ACC || (MT == 1 && NL == 16 && !GIDX), "VALU accumulate: one row, tiles of 16 lanes");
   if constexpr (NO_SMALL) {
 #pragma unroll
     for (int r = 0; r < SI; ++r) {
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(64 * NW)
       }
     }
   };
-  auto wact_store = [&]() {
+  auto wact_store = [&](uint32_t u) {
     __builtin_amdgcn_wave_barrier();  // the previous unit's reads of this region come first
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
@@ -358,6 +371,11 @@ __global__ void __launch_bounds__(64 * NW)
         h[4 * q + 1] = wa_raw[r][q].y;
         h[4 * q + 2] = wa_raw[r][q].z;
         h[4 * q + 3] = wa_raw[r][q].w;
+      }
+      if (p.k & 7u) {  // wave-uniform.  A row length that is no multiple of 8: the piece that holds element k - 1 read on into the next row
+        const int left = (int)p.k - (int)(u * (uint32_t)(LK * UB * 32) + cu * (uint32_t)CHK);  // elements of this chunk inside the row
+#pragma unroll
+        for (int d = 0; d < CHK / 2; ++d) h[d] = left >= 2 * d + 2 ? h[d] : (left == 2 * d + 1 ? (h[d] & 0xFFFFu) : 0u);
       }
 #pragma unroll
       for (int q = 0; q < CPT; ++q) {
@@ -604,9 +622,16 @@ __global__ void __launch_bounds__(64 * NW)
         }
       }
     });
+    if constexpr (VALU_ACC) {
 #pragma unroll
-    for (int c = 0; c < CPL; ++c)
-      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c][0] = __builtin_amdgcn_fdot2(as_h2(braw[c][e]), as_h2(araw[e]), acc[c][0], false);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
+    }
     if constexpr (MT == 32) {  // rows 16-31: the same B fragments once more
       const u32x4_t araw_hi = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OSTEP + 64);
       const h8_t a_hi = __builtin_bit_cast(h8_t, araw_hi);
@@ -637,7 +662,7 @@ __global__ void __launch_bounds__(64 * NW)
     const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : (zero_lane ? s_zero : s_act + (cur - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane);
     uint32_t gq[GIDX ? UB : 1][16];
     if constexpr (WAVEACT) {
-      if (live) wact_store();  // this unit's activations: requested one unit ago, the oldest loads in flight
+      if (live) wact_store(cur);  // this unit's activations: requested one unit ago, the oldest loads in flight
       wact_issue(nxt);         // the next unit's: in front of every row this unit will request for it
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -679,7 +704,7 @@ __global__ void __launch_bounds__(64 * NW)
       for (int i = 0; i < R; ++i) rs[i].load(r_w, lane_off, u * unit_bytes + (uint32_t)i * row_bytes);
       if constexpr (WAVEACT) {
         wact_issue(u);
-        wact_store();
+        wact_store(u);
       }
       const uint32_t* const a_unit = WAVEACT ? my_act + a_lane : (zero_lane ? s_zero : s_act + (u - ubeg) * (uint32_t)(LK * UB * 16 * MT) + a_lane);
       static_for<S>([&](auto s_c) { step(rs, a_unit, s_c, std::false_type{}, s2, nzs2, ss2, gq); });
@@ -693,6 +718,15 @@ __global__ void __launch_bounds__(64 * NW)
   // ---- cross-wave sum.  D[row][slot]: row 4 * (lane >> 4) + r lives in register r of lane (lane >> 4, slot = lane & 15).
   // NL = 16: rows 0..MT-1 (registers 0..MT-1 of lanes 0-15) are the sums over the wave's four k-slots for column slot = nl.
   // NL = 8: even k-slots sum into D[m][0..7] (lanes 0-7), odd ones into D[8 + m][8..15] (lanes 40-47). ----
+  if constexpr (VALU_ACC) {  // the four k-slots of a column, then where the MFMA build has the sum: register 0 of lanes 0-15
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      float v = acc[c][0];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[c][0] = v;
+    }
+  }
   if constexpr (NO_SUM) {  // lab ablation: every wave stores its own partial sums, no LDS, no barrier
     if (lane < 16 && col_ok) {
 #pragma unroll
@@ -702,6 +736,7 @@ __global__ void __launch_bounds__(64 * NW)
     return;
   }
   {
+    if constexpr (ALIAS) __syncthreads();  // every wave is done with its activations
     // NL = 32: column set 0 in rows 0.. (lanes 0-15), column set 1 in rows 8.. (lanes 32-47)
     const int h = NL >= 16 ? 0 : (lane >= 32 ? 1 : 0);
     const bool holder = NL == 16 ? lane < 16 : (NL == 32 ? (lane < 16 || (lane >= 32 && lane < 48)) : (lane < 8 || (lane >= 40 && lane < 48)));
@@ -784,7 +819,9 @@ inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl, int mt)
   const int hs = nl >= 16 ? 1 : 16 / nl, cn = nl * cpl;
   // act-order: group ids (2 B per k) beside the activations and a second table for the spliced form
   const size_t ids = p.by_id ? (size_t)p.id_bytes : 0u, tables = p.by_id ? 2u : 1u;
-  return (size_t)p.act_bytes + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u + 32u + (nl == 32 ? (size_t)(2 * 16 * mt * 4) : 0u);
+  const size_t red = (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u;
+  const size_t act_and_red = mt == 32 ? ((size_t)p.act_bytes > red ? (size_t)p.act_bytes : red) : (size_t)p.act_bytes + red;  // 32 rows: the scratch reuses the activation region
+  return act_and_red + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + 32u + (nl == 32 ? (size_t)(2 * 16 * mt * 4) : 0u);
 }
 
 constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
@@ -798,10 +835,10 @@ constexpr int dyn_ub() {
 }
 
 // NW waves per workgroup, the older half of them staging (8 / 4 everywhere but the 128-column tiles, which run 16 / 8: one workgroup per CU there)
-template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1, int NW = kDynWaves, bool MULTI = false>
+template <int BITS, int CPL, int NL, bool NT, int SI, int FLAGS = 0, bool SPLIT = false, bool GIDX = false, int MT = 1, int NW = kDynWaves, bool MULTI = false, int LA = kDynLookahead>
 int launch_dyn_one(const DynParams& p, hipStream_t stream) {
   constexpr int UB = dyn_ub<BITS>();
-  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, NW, NT, SI, NW / 2, kDynLookahead, FLAGS, SPLIT, GIDX, MT, MULTI>;
+  auto kern = gemv_dyn_kernel<BITS, UB, CPL, NL, NW, NT, SI, NW / 2, LA, FLAGS, SPLIT, GIDX, MT, MULTI>;
   static_assert(kDynStagers == kDynWaves / 2, "the older half stages");
   DynParams q = p;
   GemvSets sets = {};
@@ -817,6 +854,13 @@ constexpr int kDynWideWaves = 16;
 template <int BITS, bool NT>
 int launch_dyn_wide(const DynParams& p, hipStream_t stream, uint32_t rounds) {
   if constexpr (BITS == 4 || BITS == 8) {
+#if XBIT_TUNING
+    if (p.wide_probe != 0u && p.mt == 1u && !p.by_id && rounds <= 4u) {  // measurement builds (variants 344-347): K split over workgroups, eight waves, deeper lookahead
+      if (p.splits > 1u) return p.wide_probe == 2u ? launch_dyn_one<BITS, 4, 32, NT, 4, 0, true, false, 1, 8>(p, stream) : launch_dyn_one<BITS, 4, 32, NT, 4, 0, true, false, 1, kDynWideWaves>(p, stream);
+      if (p.wide_probe == 2u) return launch_dyn_one<BITS, 4, 32, NT, 4, 0, false, false, 1, 8>(p, stream);
+      if (p.wide_probe == 3u) return launch_dyn_one<BITS, 4, 32, NT, 4, 0, false, false, 1, kDynWideWaves, false, 6>(p, stream);
+    }
+#endif
     if (p.by_id || p.splits > 1u || p.mt > 4u) return kDynNotEligible;
     if (p.mt > 1u) {
       if (rounds <= 2u) return launch_dyn_one<BITS, 4, 32, NT, 2, 0, false, false, 4, kDynWideWaves>(p, stream);
@@ -852,7 +896,10 @@ template <int BITS, int CPL, int NL, bool NT>
 int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool stamped) {
 #if XBIT_TUNING
   if (stamped) {
-    if (rounds <= 2u && p.splits <= 1u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 2>(p, stream);
+    if (rounds <= 2u && p.splits <= 1u && p.mt == 1u && !p.by_id) {
+      if (p.trace != nullptr) return launch_dyn_one<BITS, CPL, NL, NT, 2, 2>(p, stream);
+      if constexpr (NL == 16) return launch_dyn_one<BITS, CPL, NL, NT, 2, 32>(p, stream);  // "stamped" without a trace buffer: the VALU-accumulate build (variant 321)
+    }
     return kDynNotEligible;
   }
 #else
@@ -860,7 +907,7 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #endif
   if (p.by_id) {  // act-order: 48-column tiles; 1 or up to 4 rows: K up to 4096 (2 rounds) or 8192 (4 rounds); 5..16 rows: any K
     if constexpr (NL == 16 && CPL == 3) {
-      if (p.mt > 16u) return kDynNotEligible;
+      if (p.mt > 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 32>(p, stream);
       if (p.mt > 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 16>(p, stream);
       if (p.mt > 4u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 8>(p, stream);
       if (p.mt > 1u) {
@@ -927,14 +974,16 @@ template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr, uint32_t tcols = 0, const GemvSets* sets = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g.m < 1u || g.m > 32u || (g.m > 1u && (g.k % 8u != 0u || stamped))) return kDynNotEligible;  // several rows: whole 16-byte pieces per row
+  if (g.m < 1u || g.m > 32u || (g.m > 1u && stamped)) return kDynNotEligible;  // (a row length that is no multiple of 8 is masked where it is staged)
   if (g.m > 4u && nl != 16) return kDynNotEligible;                              // 5..32 rows: tiles of 16 lanes
   if (sets != nullptr && (nl != 16 || (cpl != 3 && cpl != 4) || g.m > 16u || g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || stamped || tcols != 0u ||
                           sets->count < 1u || sets->count > (uint32_t)kMaxMulti))
     return kDynNotEligible;  // fused launches: 48- or 64-column tiles, whole K, contiguous groups
-  if (nl == 32 && (cpl != 4 || g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || stamped)) return kDynNotEligible;  // 128-column tiles: 16-byte lanes, whole K
+  const uint32_t wide_probe = XBIT_TUNING ? tcols >> 16 : 0u;  // tuning builds: measurement build of the 128-column tiles, carried in the upper half of tcols
+  tcols &= 0xFFFFu;
+  if (nl == 32 && (cpl != 4 || g_idx != nullptr || g.groupsize % 32u != 0u || (splits > 1u && wide_probe == 0u) || stamped)) return kDynNotEligible;  // 128-column tiles: 16-byte lanes, whole K
   if (g.m > 16u && splits > 1u) return kDynNotEligible;                          // 17..32 rows keep K whole
-  if (g.m > 16u && (g_idx != nullptr || g.groupsize % 32u != 0u)) return kDynNotEligible;  // 17..32 rows: contiguous groups
+  // 17..32 rows by id (act-order, odd group sizes): the 32-row by-id build
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
   // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column
   // tiles, whole K, every group in the LDS table.
@@ -948,7 +997,8 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   } else if (g.groupsize % (32u * UB) != 0u || (dq & (dq - 1u)) != 0u) {
     return kDynNotEligible;  // multiples of 32 the table-per-k-slot scheme cannot index (96, or 32 at 2 bits): xbit_gemv_mfma.h
   }
-  if (((uintptr_t)g.a | (uintptr_t)g.qweight | (uintptr_t)g.scales | (uintptr_t)g.qzeros) % 4u != 0u) return kDynNotEligible;  // dword buffer loads
+  // activations and scales may sit on any halfword (unaligned dword loads are served: profiles/r04/unaligned_probe.txt); the packed words are int32
+  if (((uintptr_t)g.qweight | (uintptr_t)g.qzeros) % 4u != 0u || ((uintptr_t)g.a | (uintptr_t)g.scales) % 2u != 0u) return kDynNotEligible;
   const uint32_t d = by_id ? 1u : dq;
   if (nl != 16 && !(nl == 8 && cpl == 2) && !(nl == 32 && cpl == 4)) return kDynNotEligible;
   // columns a tile owns: the whole lane map unless the caller narrows it (a multiple of cpl: every lane is all in or all out)
@@ -977,6 +1027,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   const uint32_t lk = 64u / (uint32_t)nl, kblocks = (g.k + 31u) / 32u;
   p.tcols = tcols;
   p.tiles = (g.n + tcols - 1u) / tcols;
+  p.wide_probe = wide_probe;
   p.sets = nullptr;
   GemvSets fused;
   if (sets != nullptr) {  // the grid: every set's tiles, one after the other
@@ -984,7 +1035,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
     uint32_t end = 0;
     for (uint32_t j = 0; j < (uint32_t)kMaxMulti; ++j) {
       if (j < fused.count) {
-        if (((uintptr_t)fused.qweight[j] | (uintptr_t)fused.scales[j] | (uintptr_t)fused.qzeros[j]) % 4u != 0u || fused.n[j] == 0u || fused.n[j] > g.n) return kDynNotEligible;
+        if (((uintptr_t)fused.qweight[j] | (uintptr_t)fused.qzeros[j]) % 4u != 0u || (uintptr_t)fused.scales[j] % 2u != 0u || fused.n[j] == 0u || fused.n[j] > g.n) return kDynNotEligible;
         end += (fused.n[j] + tcols - 1u) / tcols;
       }
       fused.tile_end[j] = j < fused.count ? end : 0xFFFFFFFFu;
@@ -1009,6 +1060,10 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
     p.mt = mt;
     p.act_bytes = p.ups * lk * UB * 64u * mt;
     if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
+    if (mt == 32u) {  // the reduction scratch reuses this region: it must hold kDynWaves * 32 * (nl * cpl) floats (it does: 66 KB against <= 64 KB; kept as a guard)
+      const uint32_t red = (uint32_t)kDynWaves * 32u * (uint32_t)(nl * cpl) * 4u;
+      if (p.act_bytes < red) p.act_bytes = red;
+    }
     p.id_bytes = by_id ? p.ups * lk * UB * 64u : 0u;
     // rows of the LDS table: every group a k-slot of one K range can name (a range may begin inside a group); whole-K
     // launches cover at least `groups` rows so that the zero rows past the last group exist

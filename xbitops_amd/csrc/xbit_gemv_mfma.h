@@ -32,6 +32,8 @@
 
 #include "xbit_device.h"
 #include "xbit_host.h"
+#include "xbit_launch_all.h"
+#include "xbit_gemv_rules.h"
 
 namespace xbit {
 
@@ -834,360 +836,213 @@ int launch_multi_bits(const GemvMultiParams& p, hipStream_t stream) {
   return launch_multi_one<BITS, UBMAX, 2>(p, stream, batches, tiles);
 }
 
-template <int BITS>
-int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts) {
-  constexpr int UBMAX = max_ub<BITS>();
-  const uint32_t kblocks = (p.k + 31) / 32;
-  int cpl = pick_cpl(p.n);
-  int variant = (XBIT_TUNING && opts.variant > 0) ? opts.variant : -1;  // the production library has no variants
-#if XBIT_TUNING
-  if (variant >= 112 && variant <= 114) {  // sweep hook, any M: force the tile width of the default path (32/48/64 columns)
-    cpl = variant - 110;
-    variant = -1;
-  }
-  uint32_t wave_cap = 16u;
-  if (variant == 120 || variant == 121) {  // sweep hooks, any M: the default path with at most 8 / 16 waves per workgroup
-    wave_cap = variant == 120 ? 8u : 16u;
-    variant = -1;
-  }
+// ---- the launch rule: xbit_gemv_rules.h says WHICH launch, the functions below HOW --------------------------------------------------
+
+// What a measurement build may override (xbit_gemv_tuning.h); the production library always passes the defaults.
+struct RuleHooks {
+  int cpl = 0;               // default tile width / 16 (0: pick_cpl(n))
+  uint32_t wave_cap = 16u;   // waves per workgroup of the round-2 default path
   bool force_nt = false, force_plain = false;
-  if (variant == 122 || variant == 123) {  // sweep hooks, any M: the default path with nontemporal / plain weight loads
-    force_nt = variant == 122;
-    force_plain = variant == 123;
-    variant = -1;
+  bool no_dyn = false;       // never the staged-operand kernel
+  bool no_split = false;     // never split K
+  bool no_fill_once = false; // never the fill-once split plan
+  bool scored_on_dyn = false;  // the scored split plan always on the staged-operand kernel's split build
+  int scored_cpl = 0;          // tile width / 16 of the scored plan (0: as planned)
+};
+
+template <int BITS>
+rules::Call make_call(const GemvParams& p, const RuleHooks& hooks) {
+  constexpr int UBMAX = max_ub<BITS>();
+  rules::Call c;
+  c.bits = BITS;
+  c.m = p.m;
+  c.k = p.k;
+  c.n = p.n;
+  c.groupsize = p.groupsize;
+  c.kblocks = (p.k + 31u) / 32u;
+  c.t32 = (p.n + 31u) / 32u;
+  c.cpl = hooks.cpl ? hooks.cpl : pick_cpl(p.n);
+  c.tiles = (p.n + 16u * (uint32_t)c.cpl - 1u) / (16u * (uint32_t)c.cpl);
+  c.ubmax = UBMAX;
+  c.flags = p.groupsize % (32u * UBMAX) == 0u ? rules::kGroupA : ((UBMAX > 2 && p.groupsize % 64u == 0u) ? rules::kGroupB : rules::kGroupC);
+  if (c.cpl == 2 && c.t32 < 160u && c.kblocks >= 128u) c.flags |= rules::kSmallN;
+  if ((BITS == 4 || BITS == 8) && p.n >= 25600u && c.kblocks / (uint32_t)UBMAX >= 32u) c.flags |= rules::kWide;
+  if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) c.flags |= rules::kBigWeights;
+  return c;
+}
+
+// Act::FillOnceSplit.  FILL THE CHIP ONCE: 64-column tiles of the staged-operand kernel's split-K build times as many K ranges as give at
+// most 256 workgroups (32-column tiles where that would take more than 15 ranges: N around 1024); where one round of workgroups would
+// leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192) two rounds are filled instead (x 5 = 480), with the
+// one-round plan as the fallback when the K ranges of the two-round one are too short.  2..16 rows take the same plan through the
+// split-K builds of the 4-, 8- and 16-row kernels.  One row whose K ranges exceed the split build's staging rounds (K / splits > 4096 at
+// group 128): the same plan on this file's split kernel (UB_ k-blocks per lane).
+template <int BITS, int UB_>
+int act_fill_once(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts, const rules::Call& c) {
+  const uint32_t t64 = (p.n + 63u) / 64u;
+  int fcpl = 4;
+  uint32_t tiles = t64, fsplits = 256u / t64;
+  if (fsplits > 15u) {  // narrow layers: 32-column tiles
+    fcpl = 2;
+    tiles = c.t32;
+    fsplits = 256u / c.t32 > 15u ? 15u : 256u / c.t32;
   }
-#else
-  constexpr uint32_t wave_cap = 16u;
-  constexpr bool force_nt = false, force_plain = false;
-#endif
-  // One activation row (decode): the staged-operand kernel of xbit_gemv_dyn.h wherever it is eligible and the shape is
-  // not one that splits K over workgroups or takes the very wide tiles below (measured: profiles/r03/sweep_dyn_vs_mfma.txt).
-  // Tuning builds: variant 300 forces it (automatic tile), 301 16-column tiles (8 lanes x 8 B), 302-304 tiles of 32 / 48 /
-  // 64 columns, 310-314 the same with plain instead of nontemporal row loads, 320 stamped (tools/gemv_trace_detail.py),
-  // 399 never (the whole-K kernels of this file, unsplit, for A/B), 398 never, but with this file's own launch rules (split-K
-  // included): the round-2 library.
-  bool rows16_rule = false, rows32_rule = false;  // set by the launch rule below when 5..16 / 17..32 rows go to the staged-operand kernel
-  auto try_dyn = [&](int auto_cpl, bool auto_small_n) -> int {
-    if (p.m > 32u) return kGemvDynNotEligible;
-    if (p.m > 16u && !(XBIT_TUNING && variant >= 300) && !rows32_rule) return kGemvDynNotEligible;
-    if (p.m > 4u && p.m <= 16u && !(XBIT_TUNING && variant >= 300) && !rows16_rule) return kGemvDynNotEligible;
-    if (p.m > 4u && auto_small_n && !(XBIT_TUNING && variant >= 302 && variant <= 304)) return kGemvDynNotEligible;  // 16-column tiles take one row
-    if (p.m > 1u && p.m <= 4u && (auto_small_n || !(BITS == 4 || BITS == 8)) && !(XBIT_TUNING && variant >= 300))
-      return kGemvDynNotEligible;  // the 16-column tiles take one row; 2-4 rows pay at 4 and 8 bits only (rule below)
-    int dcpl = auto_small_n ? 2 : auto_cpl, dnl = auto_small_n ? 8 : 16;
-    bool nt = true, stamped = false;
-    uint32_t tcols = 0;
-#if XBIT_TUNING
-    if (variant >= 340 && variant <= 343) {  // round 4: 128-column tiles of the staged-operand kernel (340), tiles narrowed so that their count fills the chip (341: 128-column lane map, 342 / 343: 64 / 48)
-      dcpl = variant == 343 ? 3 : 4;
-      dnl = variant <= 341 ? 32 : 16;
-      if (variant != 340) tcols = fill_tcols(p.n, (uint32_t)(dnl * dcpl), (uint32_t)dcpl);
-      return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, true, false, nullptr, 1, nullptr, nullptr, tcols);
-    }
-    if (variant == 399 || variant == 398 || (variant > 0 && (variant < 300 || variant > 320))) return kGemvDynNotEligible;
-    if (variant >= 310 && variant <= 314) nt = false;
-    const int v = variant >= 310 && variant <= 314 ? variant - 10 : variant;
-    if (v == 301) dcpl = 2, dnl = 8;
-    if (v >= 302 && v <= 304) dcpl = v - 300, dnl = 16;
-    if (variant == 320) stamped = true;
-#endif
-    return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, nt, stamped, opts.trace, 1, nullptr, nullptr, tcols);
-  };
-  // ---- split-K plan for one row on few-column, long-K layers (called from the group-size branches below) ----
-  // Few column tiles, long K: split K over workgroups (needs the per-stream workspace).
-  // One row: FILL THE CHIP ONCE - 64-column tiles of the staged-operand kernel's split-K build times as many K ranges as
-  // give at most 256 workgroups (32-column tiles where that would take more than 15 ranges: N around 1024).  An exhaustive
-  // sweep (every split factor 2..12 x both tile widths x both kernels; 41 shapes with K 8192..28672 and N 1024..5120 at 4
-  // bits, 16 each at 2 / 3 / 5 / 8 bits; profiles/r03/sweep_split_*.txt) puts this plan at the best one on most shapes
-  // and within 10 % on all, where round 2's scored planner plus its table of three measured shapes was up to 1.3 x (4-bit)
-  // and 1.95 x (5-bit 20480x2560: 17.3 against 8.9 us) off.  It also beats the table's own entries (11008x4096 w4 7.52
-  // against 7.83 us, 13824x2560 6.58 against 7.38), so the table is gone.
-  // Up to 8192 columns when K >= 12288 (8192 x N stays unsplit there: 8.8 against 9.0 us at N = 6144).  When one round of
-  // workgroups would leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192), two rounds are filled
-  // instead (x 5 = 480): 28672x6144 24.8 -> 20.3 us, 12288x6144 12.2 -> 10.9 (sweep_split_wide_shapes_*.txt).
-  // 2..16 rows take the same plan through the split-K builds of the 4-, 8- and 16-row kernels (down-projections at small
-  // batch): 11008x4096 w4 9.1 -> 7.9 us at 2 rows, 11.0 -> 8.3 at 8, 15.9 -> 9.6 at 16; 12288x3072 w8 at 16 rows 22.2 -> 11.3
-  // (profiles/r03/sweep_rows_split_k.txt; variant 336 forces it in tuning builds)
-  const bool fill_rows_rule = true;
-  auto fill_once = [&](auto ub_c) -> int {
-    constexpr int UB_ = decltype(ub_c)::value;
-    const uint32_t t32_ = (p.n + 31u) / 32u;
-    const bool rows_ok = p.m == 1u || (XBIT_TUNING && variant == 336 && p.m <= 16u) || (fill_rows_rule && p.m <= 16u);
-    if (opts.split == 0 && rows_ok && (variant <= 0 || variant == 336) && ((kblocks >= 256u && t32_ <= 176u) || (kblocks >= 384u && t32_ <= 256u)) &&
-        !((p.m == 1u || (BITS == 2 && p.m <= 4u)) && BITS <= 3 && kblocks <= 256u && p.n >= 3072u)) {  // one row of 2 / 3 bits (2-bit: up to 4 rows) at K <= 8192 with >= 3072 columns: unsplit is as good or better (8192x3584 w2 at 2 rows: 6.1 against 6.8 us)
-      const uint32_t t64 = (p.n + 63u) / 64u;
-      int fcpl = 4;
-      uint32_t tiles = t64, fsplits = 256u / t64;
-      if (fsplits > 15u) {  // narrow layers: 32-column tiles
-        fcpl = 2;
-        tiles = t32_;
-        fsplits = 256u / t32_ > 15u ? 15u : 256u / t32_;
-      }
-      uint32_t alt = 0;  // the one-round plan, tried if the two-round one is not eligible (K ranges too short)
-      if (tiles * fsplits < 205u && 512u / tiles <= 15u && tiles * (512u / tiles) >= 410u) {
-        alt = fsplits;
-        fsplits = 512u / tiles;
-      }
-      for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
-        const uint32_t mt_rows = p.m > 8u ? 16u : (p.m > 4u ? 8u : (p.m > 1u ? 4u : 1u));  // rows of the build that takes p.m
-        const size_t slots = (size_t)tiles * (size_t)(16 * fcpl) * mt_rows;
-        GemvWorkspace ws;
-        if (gemv_workspace(stream, slots, opts, &ws)) {
-          const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
-          if (st != kGemvDynNotEligible) return st;
-          if (p.m > 1u) break;  // several rows: no other kernel takes this plan
-          // K ranges beyond the split build's staging rounds (K / splits > 4096 at group 128): the same plan on this file's
-          // split kernel (28672x8192: 26.4 unsplit, 24.6 split)
-          const uint32_t batches = (kblocks + (uint32_t)UB_ - 1u) / (uint32_t)UB_;
-          if (attempt == 0 && fsplits <= batches / 8u) {
-            SplitPlan fp;
-            fp.cpl = fcpl;
-            fp.splits = fsplits;
-            return launch_plan<BITS, UB_>(p, stream, fp, ws);
-          }
-        }
-        fsplits = alt;
-        alt = 0;
+  uint32_t alt = 0;  // the one-round plan, tried if the two-round one is not eligible (K ranges too short)
+  if (tiles * fsplits < 205u && 512u / tiles <= 15u && tiles * (512u / tiles) >= 410u) {
+    alt = fsplits;
+    fsplits = 512u / tiles;
+  }
+  for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
+    const uint32_t mt_rows = p.m > 8u ? 16u : (p.m > 4u ? 8u : (p.m > 1u ? 4u : 1u));  // rows of the build that takes p.m
+    const size_t slots = (size_t)tiles * (size_t)(16 * fcpl) * mt_rows;
+    GemvWorkspace ws;
+    if (gemv_workspace(stream, slots, opts, &ws)) {
+      const int st = launch_gemv_dyn(p, BITS, stream, fcpl, 16, true, false, nullptr, fsplits, ws.acc);
+      if (st != kGemvDynNotEligible) return st;
+      if (p.m > 1u) break;  // several rows: no other kernel takes this plan
+      const uint32_t batches = (c.kblocks + (uint32_t)UB_ - 1u) / (uint32_t)UB_;
+      if (attempt == 0 && fsplits <= batches / 8u) {
+        SplitPlan fp;
+        fp.cpl = fcpl;
+        fp.splits = fsplits;
+        return launch_plan<BITS, UB_>(p, stream, fp, ws);
       }
     }
-    return kGemvDynNotEligible;
-  };
-  if (p.groupsize % (32u * UBMAX) == 0) {
-#if XBIT_TUNING
-    if (variant == 180 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 1024>(p, stream);  // 16-row pass, weights first
-    if (variant == 181 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 0>(p, stream);     // same launch, production order
-    if (variant == 189 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8>(p, stream);             // stamped (tools/gemv_trace.py --m 16)
-    if (variant == 193 && p.m > 1 && p.m <= 4) return launch_rows16_ablate<BITS, UBMAX, 3, 8, 4>(p, stream);  // 4-row pass, stamped
-    if (variant == 198 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 16384 | 32768>(p, stream);  // ... and the reduction reads unrolled and predicated
-    if (variant == 199 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 32768>(p, stream);          // whole slice, reduction reads unrolled and predicated
-    if (variant == 200 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 65536>(p, stream);         // whole slice, reduction reads unconditional + select
-    if (variant == 197 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 16384>(p, stream);         // activation slice in two parts (k-blocks 0-1, 2-3), the second behind the first weight rows
-    if (variant == 188 && p.m > 8) return launch_rows16_ablate<BITS, UBMAX, 3, 8192>(p, stream);          // activation slice fetched and staged k-block by k-block inside the step loop
-    if (variant > 0 && p.m == 1) {  // measurement variants (M = 1): tools/gemv_sweep.py, tools/README.md
-      switch (variant) {
-        case 105: return launch_la<BITS, UBMAX, 3, 16, 8, 4, lookahead_for<BITS>()>(p, stream);  // spliced unpack forced
-        case 106: return launch_la<BITS, UBMAX, 3, 16, 8, 0, lookahead_for<BITS>()>(p, stream);  // same launch, default unpack
-        case 107: return launch_m1<BITS, UBMAX, 4, 32, 16, true>(p, stream);   // 128-column tiles, nt
-        case 108: return launch_m1<BITS, UBMAX, 4, 16, 8, true>(p, stream);    // 64-column tiles, nt
-        case 109: return launch_m1<BITS, UBMAX, 3, 16, 8, false>(p, stream);   // 48-column tiles
-        default: break;
-      }
-      if constexpr (BITS == 4) {  // launch-shape variants exist for the headline bit-width only
-        switch (variant) {
-          case 21: return launch_m1<BITS, 4, 2, 16, 8, false>(p, stream);
-          case 15: return launch_m1<BITS, 4, 3, 16, 8, false>(p, stream);
-          case 22: return launch_m1<BITS, 4, 4, 16, 8, false>(p, stream);
-          case 23: return launch_m1<BITS, 4, 2, 16, 16, false>(p, stream);
-          case 24: return launch_m1<BITS, 4, 3, 16, 16, false>(p, stream);
-          case 25: return launch_m1<BITS, 4, 4, 16, 16, false>(p, stream);
-          case 11: return launch_m1<BITS, 4, 2, 16, 8, true>(p, stream);
-          case 12: return launch_m1<BITS, 4, 3, 16, 8, true>(p, stream);
-          case 13: return launch_m1<BITS, 4, 4, 16, 8, true>(p, stream);
-          case 51: return launch_m1<BITS, 4, 4, 32, 16, false>(p, stream);  // 128-column tiles
-          case 52: return launch_m1<BITS, 4, 4, 32, 16, true>(p, stream);
-          case 53: return launch_m1<BITS, 4, 4, 32, 8, false>(p, stream);
-          case 54: return launch_m1<BITS, 4, 4, 32, 8, true>(p, stream);
-          case 55: return launch_m1<BITS, 4, 3, 32, 16, true>(p, stream);   // 96-column tiles
-          case 56: return launch_m1<BITS, 4, 2, 32, 16, true>(p, stream);   // 64-column tiles, 8-byte loads
-          case 28: return launch_m1<BITS, 4, 2, 8, 8, false>(p, stream);
-          case 39: return launch_m1<BITS, 2, 2, 8, 8, false>(p, stream);
-          case 16: return launch_m1<BITS, 4, 3, 16, 8, false, 0>(p, stream);  // lookahead sweep
-          case 17: return launch_m1<BITS, 4, 3, 16, 8, false, 2>(p, stream);
-          case 18: return launch_m1<BITS, 4, 3, 16, 8, false, 6>(p, stream);
-          case 19: return launch_m1<BITS, 4, 3, 16, 8, false, 8>(p, stream);
-          case 63: return launch_la<BITS, 4, 3, 16, 8, 8, kLookahead>(p, stream);  // stamped (tools/gemv_trace.py)
-          case 64: return launch_la<BITS, 4, 3, 16, 8, 16, kLookahead>(p, stream);  // VALU accumulate (v_dot2) instead of MFMA
-          case 183: return launch_la<BITS, 4, 3, 16, 8, 1024, 4>(p, stream);     // M = 1, first weight rows ahead of the small operands
-          case 190: return launch_m1<BITS, 2, 4, 8, 8, false>(p, stream);   // 32-column tiles as 8 lanes x 16 B x 8 k-slots (1 KB per instruction), 2 k-blocks per lane
-          case 191: return launch_m1<BITS, 1, 4, 8, 8, false>(p, stream);   // ... 1 k-block per lane
-          case 192: return launch_m1<BITS, 2, 4, 8, 16, false>(p, stream);  // ... 16 waves
-          case 170: return launch_m1<BITS, 4, 3, 16, 8, false, 138>(p, stream);   // lookahead ramp 3 -> 8
-          case 171: return launch_m1<BITS, 4, 3, 16, 8, false, 148>(p, stream);   // 4 -> 8
-          case 172: return launch_m1<BITS, 4, 3, 16, 8, false, 126>(p, stream);   // 2 -> 6
-          case 173: return launch_m1<BITS, 4, 3, 16, 8, false, 146>(p, stream);   // 4 -> 6
-          case 174: return launch_m1<BITS, 4, 3, 16, 8, false, 139>(p, stream);   // 3 -> 9
-          case 175: return launch_m1<BITS, 4, 3, 16, 8, false, 128>(p, stream);   // 2 -> 8
-          case 176: return launch_m1<BITS, 4, 4, 16, 8, false, 138>(p, stream);   // 64-column tiles, 3 -> 8
-          case 177: return launch_m1<BITS, 4, 4, 16, 8, false, 126>(p, stream);   // 64-column tiles, 2 -> 6
-          case 164: return launch_m1<BITS, 4, 3, 16, 8, true, 8>(p, stream);        // nt, lookahead 8
-          // 128-column tiles (the 8192x28672 path: 32 lanes x 16 B, nontemporal): lookahead and workgroup size
-          case 236: return launch_m1<BITS, 4, 4, 32, 16, true, 2>(p, stream);
-          case 237: return launch_m1<BITS, 4, 4, 32, 16, true, 6>(p, stream);
-          case 238: return launch_m1<BITS, 4, 4, 32, 16, true, 8>(p, stream);
-          case 239: return launch_m1<BITS, 4, 4, 32, 8, true, 4>(p, stream);
-          case 240: return launch_m1<BITS, 4, 4, 32, 8, true, 6>(p, stream);
-          case 241: return launch_m1<BITS, 4, 4, 32, 8, true, 8>(p, stream);
-          case 242: return launch_m1<BITS, 4, 4, 16, 8, true, 6>(p, stream);   // 64-column tiles, nontemporal, lookahead 6
-          case 243: return launch_m1<BITS, 4, 4, 16, 8, true, 8>(p, stream);
-          case 272: return launch_la<BITS, 4, 4, 16, 8, 0, 4>(p, stream);         // 64-column tiles, 8 waves, lookahead 4
-          case 274: return launch_la<BITS, 4, 4, 32, 16, 0, 4>(p, stream);        // 128-column tiles, 16 waves, plain loads
-          case 231: return launch_la<BITS, 4, 3, 16, 8, 131072, 4>(p, stream);  // wait for a step's rows before issuing the next loads, lookahead 4
-          case 232: return launch_la<BITS, 4, 3, 16, 8, 131072, 5>(p, stream);  // ... lookahead 5 (the same 5 rows outstanding at most)
-          case 233: return launch_la<BITS, 4, 3, 16, 8, 131072, 6>(p, stream);
-          case 234: return launch_la<BITS, 4, 3, 16, 8, 131072, 8>(p, stream);
-          case 235: return launch_la<BITS, 4, 3, 16, 8, 0, 5>(p, stream);       // lookahead 5, production order
-          case 230: return launch_la<BITS, 4, 3, 16, 8, 65536, 4>(p, stream);   // reduction reads unconditional + select
-          case 229: return launch_la<BITS, 4, 3, 16, 8, 32768, 4>(p, stream);   // reduction reads unrolled and predicated
-          case 214: return launch_la<BITS, 2, 2, 8, 8, 0, 4>(p, stream);   // 16-column tiles (8 lanes x 8 B x 8 k-slots), whole K
-          case 135: return launch_m1<BITS, 4, 3, 16, 8, false, 5>(p, stream);
-          case 136: return launch_m1<BITS, 4, 4, 16, 8, false, 6>(p, stream);
-          case 137: return launch_m1<BITS, 4, 4, 16, 8, false, 2>(p, stream);
-          case 138: return launch_m1<BITS, 2, 3, 16, 16, false, 4>(p, stream);   // 16 waves x 2 k-blocks
-          case 139: return launch_m1<BITS, 2, 3, 16, 16, false, 7>(p, stream);   // ... all 8 loads of a wave up front
-          case 140: return launch_m1<BITS, 2, 3, 16, 16, false, 2>(p, stream);
-          default: break;
-        }
-      }
-    }
-#endif  // XBIT_TUNING
-    // Few column tiles, long K: split K over workgroups (needs the per-stream workspace); one row first tries the
-    // fill-the-chip-once plan (fill_once above).
-    {
-      const int st = fill_once(std::integral_constant<int, UBMAX>{});
+    fsplits = alt;
+    alt = 0;
+  }
+  return kGemvDynNotEligible;
+}
+
+// Act::ScoredSplit (and a split the caller forces through options.split_k): plan_split() picks tile width and split count.  One row whose
+// K ranges give every one of the staged-operand kernel's eight waves the same number of units, or many of them (units per range == 16 or
+// >= 24: 8192x3584 w4 6.5 -> 6.1 us, 14336x4096 8.8 -> 8.1; profiles/r03/sweep_split_dyn.txt), runs that kernel's split build; the ranges
+// of 15-18 units that the plans for K = 11008 / 13824 use run this file's (11008x4096 7.8 against 8.6).  Group size 64 (UB_ == 2 with
+// max_ub == 4): this file's split kernel only.
+template <int BITS, int UB_>
+int act_scored_split(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts, const rules::Call& c, const RuleHooks& hooks) {
+  SplitPlan plan = plan_split(p, UB_, opts.split, BITS);
+  if (plan.splits < 2u) return kGemvDynNotEligible;
+  if (hooks.scored_cpl) plan.cpl = hooks.scored_cpl;
+  const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
+  const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
+  GemvWorkspace ws;
+  if (!gemv_workspace(stream, slots, opts, &ws)) return kGemvDynNotEligible;
+  if (UB_ == max_ub<BITS>() && p.m == 1u && !hooks.no_dyn) {
+    const uint32_t dyn_units = (c.kblocks + (BITS == 2 ? 8u : 4u) - 1u) / (BITS == 2 ? 8u : 4u), dyn_ups = (dyn_units + plan.splits - 1u) / plan.splits;
+    if (hooks.scored_on_dyn || dyn_ups == 16u || dyn_ups >= 24u) {
+      const int st = launch_gemv_dyn(p, BITS, stream, plan.cpl, 16, true, false, nullptr, plan.splits, ws.acc);
       if (st != kGemvDynNotEligible) return st;
     }
-    {
-      SplitPlan plan = plan_split(p, UBMAX, opts.split, BITS);
-      // 2- and 3-bit at K <= 8192 with >= 3072 columns: the unsplit staged-operand kernel on 16-column tiles beats every
-      // split (8192x3584 w2 5.5 against 6.1 us, 8192x4096 w3 6.0 against 6.5; sweep_split_dyn.txt)
-      if (opts.split == 0 && p.m == 1u && BITS <= 3 && kblocks <= 256u && p.n >= 3072u && variant <= 0) plan.splits = 0;
-      if (variant == 206 && plan.splits >= 2) {  // measurement: 32-column tiles read as 8 lanes x 16 B (NL = 8), split as planned
-        const uint32_t tiles = (p.n + 31u) / 32u;
-        const size_t slots = (size_t)tiles * 32u;
-        GemvWorkspace ws;
-        if (p.m == 1 && gemv_workspace(stream, slots, opts, &ws)) return launch_split_rows<BITS, 2, 4, 8, 8>(p, stream, plan.splits, ws);
-      }
-      if ((variant == 202 || variant == 205 || variant == 332 || variant == 334) && plan.splits >= 2) {  // sweep hooks (tuning builds): force the tile width
-        plan.cpl = (variant == 202 || variant == 332) ? 2 : 4;
-      } else if (variant > 0 && variant != 398 && variant != 330) {
-        plan.splits = 0;  // another measurement variant was asked for
-      }
-      if (plan.splits >= 2) {
-        const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
-        const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
-        GemvWorkspace ws;
-        if (gemv_workspace(stream, slots, opts, &ws)) {
-          // one row: the same plan through the staged-operand kernel's split-K build (tuning builds: variants 330 / 332 /
-          // 334 force it with the planned / 32-column / 64-column tiles, 398 keeps this file's kernel)
-          // Production rule (chain periods, profiles/r03/sweep_split_dyn.txt): the staged-operand build wins where every one
-          // of its eight waves gets the same number of units or many of them (units per K range == 16 or >= 24: 8192x3584
-          // w4 6.5 -> 6.1 us, 14336x4096 8.8 -> 8.1, 28672x4096 14.0 -> 13.1, 16384x1024 5.7 -> 4.9) and loses on the
-          // ranges of 15-18 units that the plans for K = 11008 / 13824 use (11008x4096 7.8 against 8.6).
-          const uint32_t dyn_units = (kblocks + (BITS == 2 ? 8u : 4u) - 1u) / (BITS == 2 ? 8u : 4u), dyn_ups = (dyn_units + plan.splits - 1u) / plan.splits;
-          const bool by_rule = dyn_ups == 16u || dyn_ups >= 24u;
-          const bool dyn_split = XBIT_TUNING ? (variant == 330 || variant == 332 || variant == 334 || (variant <= 0 && by_rule)) : by_rule;
-          if (p.m == 1u && dyn_split) {
-            const int st = launch_gemv_dyn(p, BITS, stream, plan.cpl, 16, true, false, nullptr, plan.splits, ws.acc);
-            if (st != kGemvDynNotEligible) return st;
-          }
-          return launch_plan<BITS, UBMAX>(p, stream, plan, ws);
-        }
-      }
+  }
+  return launch_plan<BITS, UB_>(p, stream, plan, ws);
+}
+
+// Act::DynChunks32: 33..128 rows in launches of 32 (each streams the weights once more), still ahead of 16-row passes and of dequantise +
+// dense GEMM (profiles/r03/linear_crossover_after_chunks_of_32.txt).  Every chunk is checked before the first is launched.
+template <int BITS>
+int act_dyn_chunks(const GemvParams& p, hipStream_t stream, int cpl) {
+  GemvParams q = p;
+  return launch_all_or_nothing([&]() -> int {
+    int s = XBIT_OK;
+    for (uint32_t r0 = 0; r0 < p.m && s == XBIT_OK; r0 += 32u) {
+      q.m = p.m - r0 < 32u ? p.m - r0 : 32u;
+      q.a = p.a + (size_t)r0 * p.k;
+      q.out = p.out + (size_t)r0 * p.n;
+      s = launch_gemv_dyn(q, BITS, stream, cpl, 16, true, false, nullptr);
     }
-    {
-      // Where the staged-operand kernel wins (chain period, profiles/r03/sweep_dyn_vs_mfma_period.txt): column tiles for
-      // most of the chip (>= 192 whole-K tiles, or the 16-column tiles of few-column layers from 3 bits up), and the
-      // wide-word widths everywhere (5/6/7-bit: 4096x14336 17.8 -> 9.0 us at 5 bits).  Not 2-bit with few columns
-      // (4096x4096: 4.1 against 4.5 us), not the 128-column-tile shapes of 4/8-bit below, not 160-tile layers at 2-4 and
-      // 8 bits (5120x5120 w4: 6.4 against 7.4: ten waves per workgroup there against this kernel's eight).  Two to four
-      // rows (the 4-row build): 4- and 8-bit only, a few per cent (4096x11008 M=4: w4 7.75 -> 7.52, w8 11.7 -> 10.9; 3-bit
-      // loses 0.2-1.5 us to its longer unpack beside four rows of activations; profiles/r03/sweep_rows_2_to_4.txt).
-      const bool small_n = cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128;
-      const bool wide = (BITS == 4 || BITS == 8) && p.n >= 25600u && kblocks / UBMAX >= 32;
-      const uint32_t dyn_tiles = (p.n + 16u * cpl - 1) / (16u * cpl);
-      // Five to sixteen rows (the 8- and 16-row builds: every wave fetches its own next unit's activations): wherever the
-      // tiles are 32 columns and more, every width - 4096x11008 w4 8.3 -> 7.6 us at 8 rows and 9.2 -> 8.6 at 16, 5120x13824
-      // 13.5 -> 10.0 and 15.3 -> 11.6, 8192x8192 11.3 -> 9.8 and 13.4 -> 11.8 (profiles/r03/sweep_rows_8_16*.txt); not
-      // where 128-column tiles serve up to 8 rows (8192x28672 w4: 25.4 against 27.8).
-      // Few-column layers: up to 8 rows stay on the 16-column tiles of this file; 9..16 rows take 32-column tiles there
-      // (4096x4096 w4 7.3 -> 6.5 us, 8192x3584 12.2 -> 11.0).
-      // Not long K on few tiles (13824x5120, 160 tiles: 17.3 -> 19.2 us at 8 rows - this file's passes run up to 14 waves
-      // per workgroup there; sweep_rows_5_16_rule_check_before_long_k_exclusion.txt).
-      // Checked on shapes no earlier sweep held (profiles/r03/sweep_rows_unseen_shapes.txt): 192 tiles with a long K lose a
-      // few per cent (16384x6144 w4 at 8 rows: 19.1 against 19.8), hence 224.
-      rows16_rule = p.m > 4u && p.m <= 16u && !(small_n && p.m <= 8u) && !(wide && p.m <= 8u) && (dyn_tiles >= 224u || kblocks <= 256u);
-      // Seventeen to thirty-two rows (the 32-row build: two A operands per unpacked B fragment, against two 16-row passes
-      // that unpack every weight twice): 4096x11008 w4 15.2 -> 11.5 us at 32 rows, 5120x13824 26.8 -> 16.3, 8192x8192 22.7 ->
-      // 16.8, 8192x28672 62 -> 43; not on few tiles (4096x4096 7.4 -> 8.6, 11008x4096 16.3 -> 21.1;
-      // profiles/r03/sweep_rows_17_32.txt).  33..128 rows: launches of 32 rows (each streams the weights once more), still
-      // ahead of 16-row passes (4096x11008 w4 at 64 rows: 22.1 us; dequantise + dense GEMM: 48.8, linear_crossover.txt).
-      rows32_rule = p.m > 16u && p.m <= 128u && dyn_tiles >= 192u;
-      if (p.m > 32u && (rows32_rule || (XBIT_TUNING && variant >= 300 && p.m <= 128u))) {
-        GemvParams q = p;
-        int st = XBIT_OK;
-        for (uint32_t r0 = 0; r0 < p.m && st == XBIT_OK; r0 += 32u) {
-          q.m = p.m - r0 < 32u ? p.m - r0 : 32u;
-          q.a = p.a + (size_t)r0 * p.k;
-          q.out = p.out + (size_t)r0 * p.n;
-          st = launch_gemv_dyn(q, BITS, stream, cpl, 16, true, false, nullptr);
-          if (st == kGemvDynNotEligible) break;  // the first chunk decides: nothing has been launched yet
-        }
-        if (st != kGemvDynNotEligible) return st;
-      }
-      const bool wins = p.m > 16u ? (rows32_rule && p.m <= 32u)
-                        : p.m > 4u ? rows16_rule
-                        : p.m > 1u ? ((BITS == 4 || BITS == 8) && !small_n && dyn_tiles >= 224u)  // 192 tiles (N = 6144) lose 5-7 % at K >= 6144
-                                   : small_n ? (BITS >= 3 || kblocks >= 256u) : (dyn_tiles >= 192u || (BITS >= 5 && BITS <= 7));
-      if ((wins && (!wide || p.m > 8u)) || (XBIT_TUNING && variant >= 300)) {
-        const int st = try_dyn(cpl, small_n && p.m <= 8u);
-        if (st != kGemvDynNotEligible) return st;
-      }
-    }
-    // Few tiles (e.g. the 8192x3584 shard of a 70B FFN on 8 GPUs: 112 tiles of 32 columns; 4096x4096):
-    // halve the tile width (NL = 8: 16 columns, the MFMA's column slots split into two k-slots) so
-    // twice as many CUs get work, with 2 k-blocks per lane and sweep.  Measured: 8192x3584 7.6 -> 6.8 us,
-    // 4096x4096 5.4 -> 4.5, 11008x4096 11.2 -> 8.5 (profiles/r01/sweep_k_heavy_shapes.txt).
-    if (cpl == 2 && (p.n + 31) / 32 < 160 && kblocks >= 128 && p.m <= 8)
-      return launch_rows<BITS, (UBMAX > 2 ? 2 : UBMAX), 2, 8, false>(p, stream);
-    // Very wide layers (>= 200 tiles of 128 columns: 70B FFN up/gate, lm_head): 32 lanes side by side,
-    // 16 bytes each, so a wave-instruction reads 512 contiguous bytes of two packed rows (NL = 32: two
-    // column sets share the MFMA's column slots and are kept apart by zeroed A operands, see the
-    // kernel).  With nontemporal loads: 8192x28672 23.4 -> 21.9 us, 4096x32000 14.2 -> 13.1,
-    // 4096x28672 13.7 -> 12.5 (profiles/r01/sweep_wide_tiles.txt); plain loads gain nothing.  4- and
-    // 8-bit only: the 3/5/6/7-bit unpackers hold too many words per lane at 4 columns (5-bit 19.5 ->
-    // 26.9 us on 4096x32000), 2-bit ties.
-    if constexpr (BITS == 4 || BITS == 8) {
-      if (p.n >= 25600u && p.m <= 8 && kblocks / UBMAX >= 32) return launch_rows<BITS, UBMAX, 4, 32, true>(p, stream);
-    }
-    // Weight loads are plain by default: equal to nontemporal when the weights come from HBM and ~8 %
-    // faster when they are still in the Infinity Cache (4096x11008).  Very large, wide layers cannot
-    // stay cached anyway and stream ~9 % faster nontemporal (8192x28672: 25.8 -> 23.4 us); long
-    // narrow ones (28672x8192) show no difference.  (profiles/r01/sweep_nt_large_shapes.txt)
-    if (force_nt || (!force_plain && (uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u)) return launch_cpl<BITS, UBMAX, true>(p, stream, cpl, wave_cap);
-    return launch_cpl<BITS, UBMAX>(p, stream, cpl, wave_cap);
+    return s;
+  });
+}
+
+// Act::MfmaDefault: this file's kernel on tiles of the default width.  Weight loads are plain by default: equal to nontemporal when the
+// weights come from HBM and ~8 % faster when they are still in the Infinity Cache (4096x11008); very large, wide layers cannot stay cached
+// anyway and stream ~9 % faster nontemporal (8192x28672: 25.8 -> 23.4 us; profiles/r01/sweep_nt_large_shapes.txt).
+template <int BITS>
+int act_mfma_default(const GemvParams& p, hipStream_t stream, const rules::Call& c, const RuleHooks& hooks) {
+  constexpr int UBMAX = max_ub<BITS>();
+  if (c.flags & rules::kGroupA) {
+    if (hooks.force_nt || (!hooks.force_plain && (c.flags & rules::kBigWeights))) return launch_cpl<BITS, UBMAX, true>(p, stream, c.cpl, hooks.wave_cap);
+    return launch_cpl<BITS, UBMAX>(p, stream, c.cpl, hooks.wave_cap);
   }
   if constexpr (UBMAX > 2) {
-    if (p.groupsize % 64u == 0) {
-      // group size 64 at 2-4 bits: 2 k-blocks per lane.  Few column tiles and long K split here too (4-bit 11008x4096
-      // g64: 10.5 us unsplit; profiles/r02/sweep_group_sizes.txt); the occupancy table is that of the 4-k-block builds,
-      // which hold a few registers more (conservative)
-      {
-        const int st = fill_once(std::integral_constant<int, 2>{});  // one row: the same plan as at group size 128
-        if (st != kGemvDynNotEligible) return st;
-      }
-      SplitPlan plan = (variant > 0 && variant != 398) ? SplitPlan{} : plan_split(p, 2, opts.split, BITS);
-      if (plan.splits >= 2) {
-        const uint32_t tiles = (p.n + 16u * plan.cpl - 1) / (16u * plan.cpl), mblocks = p.m == 1 ? 1u : (p.m + 3u) / 4u;
-        const size_t slots = (size_t)mblocks * tiles * (size_t)((p.m == 1 ? 1 : 4) * 16 * plan.cpl);
-        GemvWorkspace ws;
-        if (gemv_workspace(stream, slots, opts, &ws)) return launch_plan<BITS, 2>(p, stream, plan, ws);
-      }
-      // unsplit at group size 64 (profiles/r03/sweep_group_sizes_*.txt): the staged-operand kernel wins at 4 bits on many
-      // tiles (4096x11008 7.5 -> 7.3 us) and loses at 3 bits and on few tiles (4096x4096 w3 5.4 against 5.9)
-      if ((BITS == 4 && (p.n + 16u * cpl - 1) / (16u * cpl) >= 192u) || p.m > 1u || (XBIT_TUNING && variant >= 300)) {
-        const int st = try_dyn(cpl, false);
-        if (st != kGemvDynNotEligible) return st;
-      }
-      return launch_cpl<BITS, 2>(p, stream, cpl);
-    }
+    if (c.flags & rules::kGroupB) return launch_cpl<BITS, 2>(p, stream, c.cpl);
   }
-  // group size 32 (or 32 x odd): one table row per k-block - the staged-operand kernel loses 4-14 % at 3 and 4 bits
-  // (4096x11008 w3 7.6 against 8.7 us) and ties at 8
-  if (BITS >= 5 || p.m > 1u || (XBIT_TUNING && variant >= 300)) {
-    const int st = try_dyn(cpl, false);
+  return launch_cpl<BITS, 1>(p, stream, c.cpl);
+}
+
+template <int BITS>
+int launch_by_rules(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts, const RuleHooks& hooks = RuleHooks()) {
+  constexpr int UBMAX = max_ub<BITS>();
+  const rules::Call c = make_call<BITS>(p, hooks);
+  const bool group_a = (c.flags & rules::kGroupA) != 0u;
+  uint32_t state = 0;
+  if (opts.split >= 2 && !hooks.no_split && !(c.flags & rules::kGroupC)) {  // a split the caller asked for: no bucket decides
+    const int st = group_a ? act_scored_split<BITS, UBMAX>(p, stream, opts, c, hooks) : act_scored_split<BITS, 2>(p, stream, opts, c, hooks);
     if (st != kGemvDynNotEligible) return st;
   }
-  return launch_cpl<BITS, 1>(p, stream, cpl);
+  for (int i = 0; i < rules::kRuleCount; ++i) {
+    const rules::Rule& r = rules::kRules[i];
+    if (!rules::matches(r, c, state)) continue;
+    int st = kGemvDynNotEligible;
+    switch (r.act) {
+      case rules::Act::MarkUnsplit:
+        state |= rules::kNoFillOnce | rules::kNoScored;
+        break;
+      case rules::Act::MarkNoFillOnce:
+        state |= rules::kNoFillOnce;
+        break;
+      case rules::Act::FillOnceSplit:
+        if (opts.split != 0 || hooks.no_split || hooks.no_fill_once || hooks.no_dyn) break;
+        st = group_a ? act_fill_once<BITS, UBMAX>(p, stream, opts, c) : act_fill_once<BITS, 2>(p, stream, opts, c);
+        break;
+      case rules::Act::ScoredSplit:
+        if (opts.split != 0 || hooks.no_split) break;  // (a forced split was tried above)
+        st = group_a ? act_scored_split<BITS, UBMAX>(p, stream, opts, c, hooks) : act_scored_split<BITS, 2>(p, stream, opts, c, hooks);
+        break;
+      case rules::Act::DynChunks32:
+        if (!hooks.no_dyn) st = act_dyn_chunks<BITS>(p, stream, c.cpl);
+        break;
+      case rules::Act::DynWhole:
+        if (!hooks.no_dyn) st = launch_gemv_dyn(p, BITS, stream, c.cpl, 16, true, false, nullptr);
+        break;
+      case rules::Act::DynNarrow:
+        if (!hooks.no_dyn) st = launch_gemv_dyn(p, BITS, stream, 2, 8, true, false, nullptr);
+        break;
+      case rules::Act::Mfma16Col:
+        // halve the tile width (NL = 8: 16 columns, the MFMA's column slots split into two k-slots) so twice as many CUs get work
+        st = launch_rows<BITS, (UBMAX > 2 ? 2 : UBMAX), 2, 8, false>(p, stream);
+        break;
+      case rules::Act::Mfma128Col:
+        // 32 lanes side by side, 16 bytes each: a wave-instruction reads 512 contiguous bytes of two packed rows (NL = 32: two column
+        // sets share the MFMA's column slots and are kept apart by zeroed A operands, see the kernel); nontemporal loads
+        if constexpr (BITS == 4 || BITS == 8) st = launch_rows<BITS, UBMAX, 4, 32, true>(p, stream);
+        break;
+      case rules::Act::MfmaDefault:
+        st = act_mfma_default<BITS>(p, stream, c, hooks);
+        break;
+    }
+    if (st != kGemvDynNotEligible) return st;
+  }
+  return XBIT_ERR_SHAPE;  // not reached: the last row takes every call
+}
+
+}  // namespace
+}  // namespace xbit
+
+#if XBIT_TUNING
+#include "xbit_gemv_tuning.h"  // measurement variants (options.variant): libxbitops_hip_tuning.so only
+#endif
+
+namespace xbit {
+namespace {
+
+template <int BITS>
+int launch_bits(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts) {
+#if XBIT_TUNING
+  if (opts.variant > 0) return tuning::launch_variant<BITS>(p, stream, opts);
+#endif
+  return launch_by_rules<BITS>(p, stream, opts);
 }
 
 }  // namespace

@@ -18,6 +18,7 @@
 // tile's (scale, -zero*scale) pairs, so the per-k lookups are LDS reads, not memory instructions.
 #include "xbit_device.h"
 #include "xbit_host.h"
+#include "xbit_launch_all.h"
 
 namespace xbit {
 
@@ -157,7 +158,7 @@ int launch_gemv_gidx_bits(const GemvGidxParams& p, hipStream_t stream) {
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
   if (bits < 2 || bits > 8) return XBIT_ERR_BITS;
   if (p.m > 65535u) return XBIT_ERR_SHAPE;
-  // Up to 64 rows: the act-order builds of the staged-operand kernel (xbit_gemv_dyn.h), up to 16 rows per launch - the
+  // Up to 64 rows: the act-order builds of the staged-operand kernel (xbit_gemv_dyn.h), up to 32 rows per launch - the
   // weight stream and the arithmetic of the contiguous-group kernel plus a per-pair table lookup (4096x11008 w4, one row:
   // 29.8 -> 10.0 us, 1.5x the contiguous kernel; profiles/r03/gidx_before.txt, gidx_after.txt, gidx_rows_8_16.txt).  More
   // rows, very many groups or a K beyond its staging: the kernels of this file.
@@ -173,13 +174,21 @@ int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream) {
     q.groups = p.groups;
     q.zw = p.zw;
     q.bias = p.bias;
+    // rows in launches of 32 where the 32-row build takes the layer (its LDS image grows with the groups), else of 16; every
+    // chunk is checked before the first is launched (a 1..4-row tail takes another build than the full chunks)
     int st = kGemvDynNotEligible;
-    for (uint32_t r = 0; r < p.m; r += 16u) {
-      q.m = p.m - r < 16u ? p.m - r : 16u;
-      q.a = p.a + (size_t)r * p.k;
-      q.out = p.out + (size_t)r * p.n;
-      st = launch_gemv_dyn(q, bits, stream, 3, 16, true, false, nullptr, 1, nullptr, p.g_idx);
-      if (st != XBIT_OK) break;  // a launch error, or not eligible: the kernels below then redo every row
+    for (uint32_t chunk = 32u; chunk >= 16u && st == kGemvDynNotEligible; chunk /= 2u) {
+      st = launch_all_or_nothing([&]() -> int {
+        int s = kGemvDynNotEligible;
+        for (uint32_t r = 0; r < p.m; r += chunk) {
+          q.m = p.m - r < chunk ? p.m - r : chunk;
+          q.a = p.a + (size_t)r * p.k;
+          q.out = p.out + (size_t)r * p.n;
+          s = launch_gemv_dyn(q, bits, stream, 3, 16, true, false, nullptr, 1, nullptr, p.g_idx);
+          if (s != XBIT_OK) break;
+        }
+        return s;
+      });
     }
     if (st != kGemvDynNotEligible) return st;
   }
