@@ -249,11 +249,9 @@ def offline_profile(workload_key: str, this_lib_sha: str):
 def floor_tile_shape(n: int, bits: int, batch: int):
     """The column tiles the library's launch rule walks for an N-column layer at one row (for the pure-read floor): lane-map
     width and columns owned per tile.  Mirrors the rule in xbit_gemv_mfma.h / xbit_host.h (pick_cpl, fill_tcols)."""
-    if bits in (4, 8) and n >= 25600 and batch <= 4:
-        tiles = -(-n // 128)
-        target = -(-tiles // 256) * 256
-        per = -(-n // target)
-        return 128, min(128, -(-per // 4) * 4)
+    t128 = -(-n // 128)
+    if bits in (4, 8) and n >= 21504 and 3 * t128 >= 2 * (-(-t128 // 256) * 256) and batch <= 8:
+        return 128, 0  # 128-column tiles (kWide of xbit_gemv_rules.h)
     best, best_eff = 32, -1.0
     for cpl in (2, 3, 4):
         tiles = -(-n // (16 * cpl))

@@ -192,10 +192,11 @@ def test_fill_once_split_plans_production(bits, cuda_device):
 
 @pytest.mark.parametrize("bits", range(2, 9))
 def test_split_k_with_several_rows(bits, cuda_device):
-    """Split-K builds of the 4-, 8- and 16-row kernels (few-column long-K layers at small batch: down-projections); the
-    fill-once plan forced on 2..16 rows (variant 336), against the oracle and bit-stable across launches."""
+    """Split-K builds of the 4-, 8-, 16- and 32-row kernels (few-column long-K layers at small batch: down-projections); the
+    fill-once plan on 2..32 rows (variant 336 = the production rule), against the oracle and bit-stable across launches."""
     lib = _lib.load_tuning()
-    for k, n, g, m in [(11008, 4096, 128, 2), (8192, 3584, 128, 4), (11008, 4096, 128, 8), (16384, 1030, 128, 16), (8192, 2560, 64, 5), (12288, 6144, 128, 13)]:
+    for k, n, g, m in [(11008, 4096, 128, 2), (8192, 3584, 128, 4), (11008, 4096, 128, 8), (16384, 1030, 128, 16), (8192, 2560, 64, 5), (12288, 6144, 128, 13),
+                       (11008, 4096, 128, 32), (16384, 1030, 128, 17), (8192, 3584, 128, 24)]:  # 17..32 rows: the split build of the 32-row kernel (from 3 bits up)
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 23 + k + m)
         y = _run_m(lib, p, 1, cuda_device, 336)
         _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, k, n, g, m), k=k)

@@ -5,6 +5,9 @@ CPU restatement").  CPU only - sanitizers are never run on the GPU.
   tests then run in a child interpreter that loads that build (the sanitizer runtime is pre-loaded into it);
 * the harness's host logic (xbitops_amd/csrc/xbit_harness_check.h: fp16 decoding, the reference's acceptance rules incl. the
   NaN cases, shape derivation) through a small driver built with both sanitizers.
+* the host half of the C ABI (xbitops_amd/csrc/xbit_capi.hip: argument checks, options parsing, the split-K workspace pool's
+  bookkeeping, profiling series, dry run) compiled as plain C++ against a mock HIP runtime and recording launchers
+  (tests/sanitize/capi_host_driver.cc), driven through bad arguments, capture / release / exhaustion / failure injection.
 Any report from either sanitizer aborts the child (halt_on_error, -fno-sanitize-recover) and fails the test.
 """
 import os
@@ -51,3 +54,19 @@ def test_oracle_restatement_under_asan_ubsan(tmp_path):
                        capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_capi_host_half_under_asan_ubsan(tmp_path):
+    """xbit_capi.hip holds no kernel: with the HIP runtime mocked (host memory, injectable failures, settable capture status) and the
+    other translation units' launchers replaced by recorders, its argument validation and workspace-pool bookkeeping run under both
+    sanitizers on the CPU - the code ADVICE r02 found four bugs in."""
+    inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(inc, "hip", "hip_runtime.h")):
+        pytest.skip("HIP headers are needed (declarations only)")
+    exe = str(tmp_path / "capi_host_driver")
+    cmd = ["g++", "-std=c++17"] + SAN_FLAGS + ["-D__HIP_PLATFORM_AMD__", "-I", inc, "-include", os.path.join(ROOT, "tests", "sanitize", "hip_host_shim.h"), "-w", "-x", "c++",
+           os.path.join(ROOT, "xbitops_amd", "csrc", "xbit_capi.hip"), os.path.join(ROOT, "tests", "sanitize", "capi_host_driver.cc"), "-o", exe, "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"))
+    assert r.returncode == 0 and "all expectations hold" in r.stdout, r.stdout + r.stderr[-3000:]

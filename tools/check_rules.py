@@ -37,6 +37,9 @@ POINTS = [
     (4, 2, 3072, 9216, 128), (4, 4, 6144, 16384, 128), (8, 4, 6656, 6656, 128), (3, 4, 6144, 16384, 128), (4, 8, 3072, 9216, 128), (4, 8, 6144, 2048, 128),
     (5, 8, 6656, 6656, 128), (4, 16, 6144, 16384, 128), (3, 16, 3072, 9216, 128), (4, 16, 22016, 4096, 128), (4, 16, 4096, 1536, 128), (8, 12, 6656, 6656, 128),
     (4, 32, 3072, 9216, 128), (4, 24, 6144, 16384, 128), (2, 32, 6656, 6656, 128), (4, 32, 6144, 2048, 128), (4, 64, 3072, 9216, 128), (4, 48, 6656, 6656, 128),
+    # round 4's rule edits: 128-column tiles from 21504 columns (also at several rows), 17..32 rows of a down-projection on the split build
+    (4, 4, 8192, 22016, 128), (8, 2, 4096, 22016, 128), (4, 8, 4096, 28672, 128), (4, 1, 8192, 24576, 128), (4, 24, 22016, 4096, 128), (4, 32, 10240, 2560, 128),
+    (5, 20, 16384, 3072, 128), (3, 17, 10240, 5120, 128),
 ]
 QUICK = POINTS[::4]
 

@@ -11,7 +11,7 @@ import os
 import statistics
 import sys
 
-SKIP = ("__amd_rocclr", "at::native", "elementwise", "Cijk", "sleep", "fill", "copy")  # torch / runtime helpers, never the measured kernel
+SKIP = ("__amd_rocclr", "at::native", "elementwise", "Cijk", "sleep", "fill", "copy", "floor_")  # torch / runtime helpers, never the measured kernel
 
 
 def find(root, suffix):

@@ -310,9 +310,9 @@ int xbit_gemv_f16(void* out, const void* a, const void* qweight, const void* sca
 }
 
 uint64_t xbit_gemv_workspace_bytes(uint32_t m, uint32_t n) {
-  // split launches run 1, 4, 8 or 16 rows per pass (the build that takes m: 9..12 rows need the 16-row build's 16) over
-  // tiles of 32 or 64 columns: round both up; beyond 16 rows, passes of 4
-  const uint64_t rows = m <= 1 ? 1 : (m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 16 ? 16 : (((uint64_t)m + 3) / 4) * 4)));
+  // split launches run 1, 4, 8, 16 or 32 rows per pass (the build that takes m: 9..12 rows need the 16-row build's 16) over
+  // tiles of 32 or 64 columns: round both up; beyond 32 rows, passes of 4
+  const uint64_t rows = m <= 1 ? 1 : (m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 16 ? 16 : (m <= 32 ? 32 : (((uint64_t)m + 3) / 4) * 4))));
   const uint64_t cols = (((uint64_t)n + 63) / 64) * 64;
   return rows * cols * sizeof(unsigned long long);
 }

@@ -181,7 +181,6 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
   static_assert(!WAVEACT || (NL == 16 && FLAGS == 0), "8 / 16 / 32 rows: tiles of 16 lanes");
-  static_assert(!(SPLIT && MT == 32), "32 rows keep K whole");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   // LDS: [activations: act_bytes][act-order: group ids, 2 B per k: act_bytes][table: tab_groups * NL lanes * 16 B]
   //      [act-order: the same table with plain scales, for the spliced form][reduction: NW * HS * MT * CN floats][bad flags: 8 dwords]
@@ -907,7 +906,10 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #endif
   if (p.by_id) {  // act-order: 48-column tiles; 1 or up to 4 rows: K up to 4096 (2 rounds) or 8192 (4 rounds); 5..16 rows: any K
     if constexpr (NL == 16 && CPL == 3) {
-      if (p.mt > 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 32>(p, stream);
+      if (p.mt > 16u) {  // 2-bit (2 k-blocks per unit) does not fit the 32-row builds into 256 registers: not compiled, 16 rows per launch there
+        if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 32>(p, stream);
+        return kDynNotEligible;
+      }
       if (p.mt > 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 16>(p, stream);
       if (p.mt > 4u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 8>(p, stream);
       if (p.mt > 1u) {
@@ -926,12 +928,14 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
         if constexpr (CPL == 4) {
           if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 8>(p, stream);
           if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 16>(p, stream);
+          if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 32>(p, stream);  // 17..32 rows (round 4)
         }
         return kDynNotEligible;
       }
       if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
       if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
-      return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
+      if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
+      return kDynNotEligible;  // 2-bit: no 32-row build (it would spill)
     }
     return kDynNotEligible;
   }
@@ -982,7 +986,6 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   const uint32_t wide_probe = XBIT_TUNING ? tcols >> 16 : 0u;  // tuning builds: measurement build of the 128-column tiles, carried in the upper half of tcols
   tcols &= 0xFFFFu;
   if (nl == 32 && (cpl != 4 || g_idx != nullptr || g.groupsize % 32u != 0u || (splits > 1u && wide_probe == 0u) || stamped)) return kDynNotEligible;  // 128-column tiles: 16-byte lanes, whole K
-  if (g.m > 16u && splits > 1u) return kDynNotEligible;                          // 17..32 rows keep K whole
   // 17..32 rows by id (act-order, odd group sizes): the 32-row by-id build
   // Groups by id: act-order (g_idx given), or contiguous groups that may begin inside a k-block (size no multiple of 32:
   // 16, 48, 80 ... - no other fast kernel takes those) - the same build with the ids computed in the kernel.  48-column

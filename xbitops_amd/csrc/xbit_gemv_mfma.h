@@ -866,7 +866,10 @@ rules::Call make_call(const GemvParams& p, const RuleHooks& hooks) {
   c.ubmax = UBMAX;
   c.flags = p.groupsize % (32u * UBMAX) == 0u ? rules::kGroupA : ((UBMAX > 2 && p.groupsize % 64u == 0u) ? rules::kGroupB : rules::kGroupC);
   if (c.cpl == 2 && c.t32 < 160u && c.kblocks >= 128u) c.flags |= rules::kSmallN;
-  if ((BITS == 4 || BITS == 8) && p.n >= 25600u && c.kblocks / (uint32_t)UBMAX >= 32u) c.flags |= rules::kWide;
+  {
+    const uint32_t t128 = (p.n + 127u) / 128u, filled = ((t128 + 255u) / 256u) * 256u;  // 128-column tiles, and the CU slots their rounds occupy
+    if ((BITS == 4 || BITS == 8) && p.n >= 21504u && t128 * 3u >= filled * 2u && c.kblocks / (uint32_t)UBMAX >= 32u) c.flags |= rules::kWide;
+  }
   if ((uint64_t)p.kw * p.n * 4u >= (96ull << 20) && p.n >= 16384u) c.flags |= rules::kBigWeights;
   return c;
 }
@@ -874,8 +877,8 @@ rules::Call make_call(const GemvParams& p, const RuleHooks& hooks) {
 // Act::FillOnceSplit.  FILL THE CHIP ONCE: 64-column tiles of the staged-operand kernel's split-K build times as many K ranges as give at
 // most 256 workgroups (32-column tiles where that would take more than 15 ranges: N around 1024); where one round of workgroups would
 // leave more than a fifth of the chip idle (N = 6144: 96 tiles x 2 = 192) two rounds are filled instead (x 5 = 480), with the
-// one-round plan as the fallback when the K ranges of the two-round one are too short.  2..16 rows take the same plan through the
-// split-K builds of the 4-, 8- and 16-row kernels.  One row whose K ranges exceed the split build's staging rounds (K / splits > 4096 at
+// one-round plan as the fallback when the K ranges of the two-round one are too short.  2..32 rows take the same plan through the
+// split-K builds of the 4-, 8-, 16- and 32-row kernels (17..32 rows: from 3 bits up).  One row whose K ranges exceed the split build's staging rounds (K / splits > 4096 at
 // group 128): the same plan on this file's split kernel (UB_ k-blocks per lane).
 template <int BITS, int UB_>
 int act_fill_once(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts, const rules::Call& c) {
@@ -893,7 +896,7 @@ int act_fill_once(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts&
     fsplits = 512u / tiles;
   }
   for (int attempt = 0; attempt < 2 && fsplits >= 2u; ++attempt) {
-    const uint32_t mt_rows = p.m > 8u ? 16u : (p.m > 4u ? 8u : (p.m > 1u ? 4u : 1u));  // rows of the build that takes p.m
+    const uint32_t mt_rows = p.m > 16u ? 32u : (p.m > 8u ? 16u : (p.m > 4u ? 8u : (p.m > 1u ? 4u : 1u)));  // rows of the build that takes p.m
     const size_t slots = (size_t)tiles * (size_t)(16 * fcpl) * mt_rows;
     GemvWorkspace ws;
     if (gemv_workspace(stream, slots, opts, &ws)) {

@@ -29,7 +29,8 @@ struct Call {
 
 enum : uint32_t {
   kSmallN = 1u << 0,      // fewer than 160 tiles of 32 columns (N < 5120) with K >= 4096: 16-column tiles (8 lanes side by side) put twice the workgroups on the chip
-  kWide = 1u << 1,        // 4- or 8-bit, N >= 25600, K >= 32 sweeps: 128-column tiles (32 lanes x 16 B: 512 contiguous bytes per packed row and instruction)
+  kWide = 1u << 1,        // 4- or 8-bit, N >= 21504 with 128-column tiles filling at least two thirds of their rounds of 256 CUs (168+ tiles), K >= 32 sweeps:
+                          // 128-column tiles (32 lanes x 16 B: 512 contiguous bytes per packed row and instruction)
   kBigWeights = 1u << 2,  // >= 96 MiB of packed weights and N >= 16384: nontemporal loads on the round-2 kernel
   kGroupA = 1u << 3,      // group size a multiple of 32 * ubmax (128 up to 4 bits, else 64): ubmax k-blocks per lane share one scale
   kGroupB = 1u << 4,      // up to 4 bits, group size a multiple of 64 but not of 128: 2 k-blocks per lane
@@ -81,9 +82,9 @@ constexpr Rule kRules[] = {
      "profiles/r03/sweep_split_dyn.txt (as above; the scored plan keeps its say at group size 64)"},
     {"2-bit, K <= 8192, >= 3072 columns, 2-4 rows: no fill-once split", bit_set(2, 2), 2, 4, 0, 256, 3072, kAny, 0, kAny, 0, kAny, 0, kGroupC, Act::MarkNoFillOnce,
      "profiles/r03/sweep_rows_split_k.txt (8192x3584 w2 at 2 rows: 6.1 us against 6.8)"},
-    {"fill the chip once: K >= 8192, <= 176 tiles of 32 columns, 1-16 rows", kAllBits, 1, 16, 256, kAny, 0, kAny, 0, kAny, 0, 176, 0, kGroupC | kNoFillOnce, Act::FillOnceSplit,
+    {"fill the chip once: K >= 8192, <= 176 tiles of 32 columns, 1-32 rows", kAllBits, 1, 32, 256, kAny, 0, kAny, 0, kAny, 0, 176, 0, kGroupC | kNoFillOnce, Act::FillOnceSplit,
      "profiles/r03/sweep_split_unseen_shapes_after.txt, sweep_split_known_shapes_after.txt, sweep_split_other_bits_after.txt, sweep_rows_split_k_after.txt"},
-    {"fill the chip once: K >= 12288, <= 256 tiles of 32 columns, 1-16 rows", kAllBits, 1, 16, 384, kAny, 0, kAny, 0, kAny, 177, 256, 0, kGroupC | kNoFillOnce, Act::FillOnceSplit,
+    {"fill the chip once: K >= 12288, <= 256 tiles of 32 columns, 1-32 rows", kAllBits, 1, 32, 384, kAny, 0, kAny, 0, kAny, 177, 256, 0, kGroupC | kNoFillOnce, Act::FillOnceSplit,
      "profiles/r03/sweep_split_wide_shapes_after.txt (12288x8192 12.6 -> 11.9 us, 28672x6144 24.8 -> 20.2)"},
     {"scored split plan, 1-4 rows (what the fill-once plan does not take)", kAllBits, 1, 4, 256, kAny, 0, kAny, 0, kAny, 0, 176, 0, kGroupC | kNoScored, Act::ScoredSplit,
      "profiles/r02/sweep_split_plans_fine.txt, sweep_split_plans_other_bits.txt; profiles/r03/sweep_split_dyn.txt (which kernel runs the plan)"},
@@ -103,6 +104,8 @@ constexpr Rule kRules[] = {
      "profiles/r03/sweep_rows_8_16_more.txt"},
     {"2-4 rows, 4- and 8-bit, >= 224 tiles: 4-row build", kBits48, 2, 4, 0, kAny, 0, kAny, 224, kAny, 0, kAny, kGroupA, kSmallN | kWide, Act::DynWhole,
      "profiles/r03/sweep_rows_2_to_4.txt (4096x11008 M=4: w4 7.75 -> 7.52 us, w8 11.7 -> 10.9; 3-bit loses), sweep_rows_unseen_shapes.txt (224)"},
+    {"2-4 rows, 4- and 8-bit, 192-223 tiles, K <= 4096: 4-row build", kBits48, 2, 4, 0, 128, 0, kAny, 192, 223, 0, kAny, kGroupA, kSmallN | kWide, Act::DynWhole,
+     "profiles/r04/check_rules_1.txt (3072x9216 w4 at 2 rows: 6.20 us against 6.99; 192 tiles lose only with a long K, profiles/r03/sweep_rows_unseen_shapes.txt)"},
     {"one row, few columns, from 3 bits up: 16-column tiles", bit_set(3, 8), 1, 1, 0, kAny, 0, kAny, 0, kAny, 0, kAny, kGroupA | kSmallN, 0, Act::DynNarrow,
      "profiles/r03/sweep_dyn_vs_mfma_period.txt (8192x3584 w3/w4 6.5 -> 5.9 / 6.1 us)"},
     {"one row, few columns, 2-bit, K >= 8192: 16-column tiles", bit_set(2, 2), 1, 1, 256, kAny, 0, kAny, 0, kAny, 0, kAny, kGroupA | kSmallN, 0, Act::DynNarrow,
@@ -122,7 +125,8 @@ constexpr Rule kRules[] = {
     {"few columns, up to 8 rows: 16-column tiles", kAllBits, 1, 8, 0, kAny, 0, kAny, 0, kAny, 0, kAny, kGroupA | kSmallN, 0, Act::Mfma16Col,
      "profiles/r01/sweep_k_heavy_shapes.txt (4096x4096 5.4 -> 4.5 us, 11008x4096 11.2 -> 8.5)"},
     {"very wide layers, 4- and 8-bit, up to 8 rows: 128-column tiles", kBits48, 1, 8, 0, kAny, 0, kAny, 0, kAny, 0, kAny, kGroupA | kWide, 0, Act::Mfma128Col,
-     "profiles/r01/sweep_wide_tiles.txt (8192x28672 23.4 -> 21.5 us); profiles/r04/sweep_wide_2.txt, sweep_wide_3.txt (staged-operand builds of the same tiles, narrowed tiles, split K: none faster)"},
+     "profiles/r01/sweep_wide_tiles.txt (8192x28672 23.4 -> 21.5 us); profiles/r04/sweep_wide_2.txt, sweep_wide_3.txt (staged-operand builds of the same tiles, narrowed tiles, split K: none faster), "
+     "sweep_wide_4.txt + check_rules_1.txt (N = 22016, 172 tiles: 8192x22016 w4 22.8 -> 19.2 us, 4096x22016 w8 22.7 -> 17.3; N = 16384, 128 tiles: loses)"},
     {"everything else", kAllBits, 1, kAny, 0, kAny, 0, kAny, 0, kAny, 0, kAny, 0, 0, Act::MfmaDefault,
      "profiles/r01/sweep_all_configs.txt, sweep_nt_large_shapes.txt; profiles/r02/sweep_16_vs_8_waves.txt"},
 };
