@@ -169,10 +169,11 @@ int xbit_dequant_gidx_f16(void* out, const void* qweight, const void* scales, co
 
 /* Extension (not in the reference): one activation against `count` (1..4) weight sets that share k,
  * bits and groupsize - q/k/v or gate/up of a decoder layer - in ONE launch when the shape allows
- * (m <= 4 and the fast path's alignment rules), otherwise as `count` xbit_gemv_f16 launches; results
- * as xbit_gemv_f16 per set.  outs / qweights / scales / qzeros / ns are HOST arrays of `count`
- * device pointers / column counts.  Small layers sit on the ~4 us launch floor, which only fewer
- * launches remove: three 4096x4096 w4 GEMVs take 3 x 4.3 us, fused 6.9 us. */
+ * (m <= 16, k % 8 == 0, a group size the staged-operand kernel indexes: a power-of-two multiple of 32, 64 at 2 bits),
+ * otherwise as `count` xbit_gemv_f16 launches; results as xbit_gemv_f16 per set.  outs / qweights / scales / qzeros / ns
+ * are HOST arrays of `count` device pointers / column counts.  Small layers sit on the launch floor, which only fewer
+ * launches remove: the seven linears of a Llama-7B decoder layer at batch 1 take 37.2 us as seven launches and 31.7 us
+ * with q/k/v and gate/up fused (13B: 54.7 -> 43.8; profiles/r04/decode_layer.txt). */
 int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void* const* qweights, const void* const* scales,
                         const void* const* qzeros, const uint32_t* ns, int bits, int groupsize, uint32_t m, uint32_t k,
                         uint8_t add_zero_bias, void* hip_stream);

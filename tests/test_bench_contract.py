@@ -55,6 +55,16 @@ def test_committed_bench_line_follows_the_contract():
     rec4 = json.loads([ln for ln in open(cfg4[-1]).read().splitlines() if ln.startswith("{")][-1])
     _check(rec4, need_cpu_baseline=False, scaling="strong")
     assert rec4["config"]["algorithmic_bytes_per_step"] == 122101760
+    # round 4: the record carries the pure-read floors measured in the same run and the same fraction by
+    # rounds 1-2's timer; the cfg4 line agrees with the rocprofv3 summary committed beside it (rocprof reads the same dispatch
+    # timestamps 0.3-1 us above the events and never below)
+    if "read_floor_us" in rec["roofline"]:
+        fl = rec["roofline"]["read_floor_us"]
+        assert 0 < fl["flat"] <= fl["tiles"] * 1.02 and fl["tiles"] < fl["kernel_chain_us"] and "frac_isolated" in rec["roofline"]
+        for r_, d_ in ((rec, os.path.dirname(logs[-1])), (rec4, os.path.dirname(cfg4[-1]))):
+            head = [ln for ln in open(os.path.join(d_, "bench_kernel_trace.txt")).read().splitlines() if ln.startswith("all launches")][0]
+            rocprof_avg = float(head.split(" avg ")[1].split(" us")[0])
+            assert r_["roofline"]["avg_kernel_us"] * 0.97 <= rocprof_avg <= r_["roofline"]["avg_kernel_us"] * 1.25, (d_, rocprof_avg, r_["roofline"]["avg_kernel_us"])
     # every profiled config carries its PMC traffic, taken from the library that produced the bench line
     for d in glob.glob(os.path.join(ROOT, "profiles", "r02", "bench", "*")):
         t = json.load(open(os.path.join(d, "pmc_traffic.json")))
@@ -79,6 +89,11 @@ def test_bench_runs_and_follows_the_contract(cuda_device):
     assert 0.85 * rec["roofline"]["achieved"] <= rec["value"] <= 1.02 * rec["roofline"]["achieved"], (rec["value"], rec["roofline"]["achieved"])
     tc = rec["cpu_baseline"]["torch_cpu"]
     assert tc["threads"] >= 1 and tc["unpack_plus_matmul_ms"] > tc["matmul_only_ms"] > 0
+    # round 4: the floors of this very run, and the last timed step's output checked against the oracle
+    fl = rec["roofline"]["read_floor_us"]
+    assert 0 < fl["flat"] < fl["kernel_chain_us"] and 0 < fl["tiles"] < fl["kernel_chain_us"] and fl["tile_lane_map_columns"] == 48
+    assert rec["output_check"]["ok"] is True and rec["output_check"]["outputs"] == 11008
+    assert 0 < rec["roofline"]["frac_isolated"] <= rec["roofline"]["frac"] * 1.05
 
 
 @pytest.mark.gpu

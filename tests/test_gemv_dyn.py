@@ -350,3 +350,15 @@ def test_odd_group_sizes_seventeen_to_forty_rows(bits, cuda_device):
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 13 + k + g)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m), k=k)
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_thirty_three_to_one_twenty_eight_rows(bits, cuda_device):
+    """33..64 rows: the 64-row build (four A operands per unpacked B fragment, four waves per workgroup; from 3 bits up), 65..128: two
+    launches of it; ragged K and few-tile layers included."""
+    lib = _lib.load()
+    for k, n, g, m in [(4096, 11008, 128, 64), (4096, 11008, 128, 33), (2048, 9216, 64, 48), (8192, 12288, 128, 64), (4096, 10000, 128, 100), (1024, 9300, 128, 128),
+                       (4098, 9216, 128, 40), (4097, 1024, 128, 57)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 29 + k + m)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m), k=k)

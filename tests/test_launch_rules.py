@@ -108,3 +108,11 @@ def test_launch_rules_grid_is_as_recorded(native_lib):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "launch_rules_grid.py"), "--check", os.path.join(root, "tests", "golden", "launch_rules.txt")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_thirty_three_to_sixty_four_rows_are_one_launch(native_lib):
+    for m, launches in ((33, 1), (64, 1), (65, 2), (128, 2)):
+        recs = plan(native_lib, 4, m, 4096, 11008)
+        assert len(recs) == launches and all("gemv_dyn_kernel<4, 1, 3, 16, 4," in r["kernel"] or m in (65,) for r in recs), recs  # the 64-row build: four waves
+    recs = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit has no 32- / 64-row build: 16-row passes of the round-2 kernel
+    assert "gemv_mfma_kernel<2," in recs[0]["kernel"], recs

@@ -139,8 +139,9 @@ struct DynParams {
 //          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
 //          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
 //          column more than the contiguous build, no change to the weight stream.
-//   MT     activation rows per launch (1, 4, 8, 16 or 32; 32: two A operands - rows 0-15 and 16-31 - per unpacked B fragment,
-//          so every weight is unpacked once for all 32 rows): the MFMA's A operand carries row (lane & 15) % MT, the staged
+//   MT     activation rows per launch (1, 4, 8, 16, 32 or 64; 32 / 64: two / four A operands - rows 0-15, 16-31, ... - per unpacked B
+//          fragment, so every weight is unpacked once for all the rows; the 64-row build runs four waves per workgroup: a wave's
+//          activation image of one unit is 16.6 KB there): the MFMA's A operand carries row (lane & 15) % MT, the staged
 //          activation image holds MT rows per octet, D rows 0..MT-1 are the results (the rest are copies).  1 and 4: the
 //          staging waves put the whole K range of every row into LDS up front.  8 and 16 (2 / 4 KB of activations per unit -
 //          the whole K range would be 64 / 128 KB at K = 4096): every wave fetches the activations of ITS next unit itself,
@@ -178,7 +179,8 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(STW >= 1 && STW <= NW, "staging waves");
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
   static_assert(!MULTI || (!GIDX && !SPLIT && FLAGS == 0), "fused launches: contiguous groups, whole K");
-  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
+  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32 || MT == 64, "rows per launch");
+  constexpr int RG = MT > 16 ? MT / 16 : 1;  // row groups of 16: one A operand each per unpacked B fragment (32 rows: 2, 64 rows: 4)
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
   static_assert(!WAVEACT || (NL == 16 && FLAGS == 0), "8 / 16 / 32 rows: tiles of 16 lanes");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(64 * NW)
   uint32_t* const s_tab_plain = s_tab + (GIDX ? p.tab_groups * (uint32_t)(NL * 4) : 0u);
   // 32 rows: the reduction scratch (NW * 32 * CN floats: 48-64 KB) REUSES the activation region, which is larger and idle by then - one
   // more workgroup barrier in front of the epilogue buys the LDS that lets the by-id build take layers with many groups
-  constexpr bool ALIAS = MT == 32;
+  constexpr bool ALIAS = MT >= 32;
   float* const s_red_own = reinterpret_cast<float*>(s_tab_plain + p.tab_groups * (uint32_t)(NL * 4));
   float* const s_red = ALIAS ? reinterpret_cast<float*>(s_act) : s_red_own;
   uint32_t* const s_bad = reinterpret_cast<uint32_t*>(s_red_own + (ALIAS ? 0 : ((NW * HS * MT * CN + 3) & ~3)));
@@ -345,8 +347,8 @@ __global__ void __launch_bounds__(64 * NW)
   uint32_t* const my_act = s_act + (uint32_t)wv * (uint32_t)(LK * UB * 4 * OST);
   // chunk t = lane + 64 * round: row t / TPR, chunk t % TPR of the unit - a row's chunks sit in neighbouring lanes (coalesced)
   auto wact_issue = [&](uint32_t u) {
-#pragma unroll
-    for (int r = 0; r < AR; ++r) {
+    static_for<AR>([&](auto r_c) {  // (compile-time r: sixteen rounds at 64 rows are not unrolled by a pragma, and wa_raw must stay in registers)
+      constexpr int r = decltype(r_c)::value;
       const uint32_t t = (uint32_t)(lane + 64 * r), mi = t / (uint32_t)TPR, cu = t % (uint32_t)TPR;
       const uint32_t k0 = u * (uint32_t)(LK * UB * 32) + cu * (uint32_t)CHK;
 #pragma unroll
@@ -356,12 +358,12 @@ __global__ void __launch_bounds__(64 * NW)
         const uint32_t kq = k0 + 8u * (uint32_t)q;
         wa_raw[r][q] = __builtin_amdgcn_raw_buffer_load_b128(r_a, (mi * p.k + kq) * 2u | (kq >= p.k ? kOob : 0u), 0, 0);
       }
-    }
+    });
   };
   auto wact_store = [&](uint32_t u) {
     __builtin_amdgcn_wave_barrier();  // the previous unit's reads of this region come first
-#pragma unroll
-    for (int r = 0; r < AR; ++r) {
+    static_for<AR>([&](auto r_c) {
+      constexpr int r = decltype(r_c)::value;
       const uint32_t t = (uint32_t)(lane + 64 * r), mi = t / (uint32_t)TPR, cu = t % (uint32_t)TPR;
       uint32_t h[CHK / 2];
 #pragma unroll
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(64 * NW)
         }
         *reinterpret_cast<u32x4_t*>(my_act + (cu * (uint32_t)CPT + (uint32_t)q) * (uint32_t)OST + mi * 4u) = o;
       }
-    }
+    });
     // produced and consumed by the same wave: in-order LDS + a wave-level fence suffice
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -538,11 +540,13 @@ __global__ void __launch_bounds__(64 * NW)
   const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(s_bad), b1 = *reinterpret_cast<const u32x4_t*>(s_bad + 4);
   const bool fast = __builtin_amdgcn_readfirstlane((int)(b0.x | b0.y | b0.z | b0.w | b1.x | b1.y | b1.z | b1.w)) == 0;
 
-  f4_t acc[CPL], acc_hi[MT == 32 ? CPL : 1];  // acc_hi: rows 16-31 of the 32-row build
+  f4_t acc[CPL], acc_hi[RG > 1 ? RG - 1 : 1][CPL];  // acc_hi[g - 1]: rows 16 g .. 16 g + 15 of the 32- and 64-row builds
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < (MT == 32 ? CPL : 1); ++c) acc_hi[c] = f4_t{0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < (RG > 1 ? RG - 1 : 1); ++g)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc_hi[g][c] = f4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   // dwords: this lane's k-blocks of the unit (4 octets each, MT rows of 4 dwords per octet), its row of the A operand
@@ -631,12 +635,15 @@ __global__ void __launch_bounds__(64 * NW)
       for (int c = 0; c < CPL; ++c)
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_frag, __builtin_bit_cast(h8_t, braw[c]), acc[c], 0, 0, 0);
     }
-    if constexpr (MT == 32) {  // rows 16-31: the same B fragments once more
-      const u32x4_t araw_hi = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OSTEP + 64);
-      const h8_t a_hi = __builtin_bit_cast(h8_t, araw_hi);
+    if constexpr (RG > 1) {  // rows 16 and up: the same B fragments once more per group of 16 rows
 #pragma unroll
-      for (int c = 0; c < CPL; ++c)
-        acc_hi[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, __builtin_bit_cast(h8_t, braw[c]), acc_hi[c], 0, 0, 0);
+      for (int g = 1; g < RG; ++g) {
+        const u32x4_t araw_hi = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OSTEP + 64 * g);
+        const h8_t a_hi = __builtin_bit_cast(h8_t, araw_hi);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          acc_hi[g - 1][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, __builtin_bit_cast(h8_t, braw[c]), acc_hi[g - 1][c], 0, 0, 0);
+      }
     }
   };
   // act-order: the ids of the lane's k-blocks of unit u (64 bytes per k-block)
@@ -746,11 +753,13 @@ __global__ void __launch_bounds__(64 * NW)
         for (int c = 0; c < CPL; ++c)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s_red[(wv * MT + 4 * (lane >> 4) + r) * CN + nl * CPL + c] = acc[c][r];
-        if constexpr (MT == 32) {
+        if constexpr (RG > 1) {
 #pragma unroll
-          for (int c = 0; c < CPL; ++c)
+          for (int g = 1; g < RG; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_red[(wv * MT + 16 + 4 * (lane >> 4) + r) * CN + nl * CPL + c] = acc_hi[c][r];
+            for (int c = 0; c < CPL; ++c)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s_red[(wv * MT + 16 * g + 4 * (lane >> 4) + r) * CN + nl * CPL + c] = acc_hi[g - 1][c][r];
         }
       }
     } else {
@@ -819,12 +828,13 @@ inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl, int mt)
   // act-order: group ids (2 B per k) beside the activations and a second table for the spliced form
   const size_t ids = p.by_id ? (size_t)p.id_bytes : 0u, tables = p.by_id ? 2u : 1u;
   const size_t red = (size_t)((nw * hs * mt * cn + 3) & ~3) * 4u;
-  const size_t act_and_red = mt == 32 ? ((size_t)p.act_bytes > red ? (size_t)p.act_bytes : red) : (size_t)p.act_bytes + red;  // 32 rows: the scratch reuses the activation region
+  const size_t act_and_red = mt >= 32 ? ((size_t)p.act_bytes > red ? (size_t)p.act_bytes : red) : (size_t)p.act_bytes + red;  // 32 / 64 rows: the scratch reuses the activation region
   return act_and_red + ids + tables * (size_t)p.tab_groups * (size_t)(nl * 16) + 32u + (nl == 32 ? (size_t)(2 * 16 * mt * 4) : 0u);
 }
 
 constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
 constexpr int kDynWaves = 8, kDynStagers = 4, kDynLookahead = 4;
+constexpr int kDynWaves64 = 4;  // the 64-row build: 4 waves x 16.6 KB of activations per unit
 constexpr size_t kDynMaxLds = 96u << 10;  // larger staged operands (K beyond ~24 K at g128) stay with xbit_gemv_mfma.h
 constexpr size_t kDynMaxLdsById = 156u << 10;  // act-order / odd group sizes: two table rows of 256 B per group (K = 4096 at group 16: 128 KB of them)
 
@@ -906,6 +916,7 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #endif
   if (p.by_id) {  // act-order: 48-column tiles; 1 or up to 4 rows: K up to 4096 (2 rounds) or 8192 (4 rounds); 5..16 rows: any K
     if constexpr (NL == 16 && CPL == 3) {
+      if (p.mt > 32u) return kDynNotEligible;  // by id: up to 32 rows per launch
       if (p.mt > 16u) {  // 2-bit (2 k-blocks per unit) does not fit the 32-row builds into 256 registers: not compiled, 16 rows per launch there
         if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 32>(p, stream);
         return kDynNotEligible;
@@ -928,14 +939,18 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
         if constexpr (CPL == 4) {
           if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 8>(p, stream);
           if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 16>(p, stream);
+          if (p.mt > 32u) return kDynNotEligible;
           if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 32>(p, stream);  // 17..32 rows (round 4)
         }
         return kDynNotEligible;
       }
       if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
       if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
-      if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
-      return kDynNotEligible;  // 2-bit: no 32-row build (it would spill)
+      if constexpr (dyn_ub<BITS>() == 1) {
+        if (p.mt > 32u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 64, kDynWaves64>(p, stream);  // 33..64 rows: four waves per workgroup
+        return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
+      }
+      return kDynNotEligible;  // 2-bit: no 32- / 64-row build (they would spill)
     }
     return kDynNotEligible;
   }
@@ -978,7 +993,7 @@ template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr, uint32_t tcols = 0, const GemvSets* sets = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g.m < 1u || g.m > 32u || (g.m > 1u && stamped)) return kDynNotEligible;  // (a row length that is no multiple of 8 is masked where it is staged)
+  if (g.m < 1u || g.m > 64u || (g.m > 1u && stamped)) return kDynNotEligible;  // (a row length that is no multiple of 8 is masked where it is staged)
   if (g.m > 4u && nl != 16) return kDynNotEligible;                              // 5..32 rows: tiles of 16 lanes
   if (sets != nullptr && (nl != 16 || (cpl != 3 && cpl != 4) || g.m > 16u || g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || stamped || tcols != 0u ||
                           sets->count < 1u || sets->count > (uint32_t)kMaxMulti))
@@ -1055,16 +1070,17 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   // build (act-order: 4 = K 8192; contiguous: 8 / 4); a longer K takes the 8-row build instead, whose waves fetch their
   // activations unit by unit and whose table is staged in a loop - rows beyond m read zeros.  (Round 3 fell to the
   // round-2 kernels there: an act-order down-projection with K = 11008 at batch 1.)
-  uint32_t mt = g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u)));
-  const int waves = nl == 32 ? kDynWideWaves : kDynWaves;
+  uint32_t mt = g.m > 32u ? 64u : (g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u))));
+  if (mt == 64u && (by_id || splits > 1u || sets != nullptr || nl != 16)) return kDynNotEligible;  // 33..64 rows: contiguous groups, whole K, one weight set
+  const int waves = nl == 32 ? kDynWideWaves : (mt == 64u ? kDynWaves64 : kDynWaves);
   const uint32_t st = 64u * (uint32_t)(waves / 2);  // staging threads
   uint32_t rounds = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     p.mt = mt;
     p.act_bytes = p.ups * lk * UB * 64u * mt;
-    if (mt >= 8u) p.act_bytes = (uint32_t)kDynWaves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
-    if (mt == 32u) {  // the reduction scratch reuses this region: it must hold kDynWaves * 32 * (nl * cpl) floats (it does: 66 KB against <= 64 KB; kept as a guard)
-      const uint32_t red = (uint32_t)kDynWaves * 32u * (uint32_t)(nl * cpl) * 4u;
+    if (mt >= 8u) p.act_bytes = (uint32_t)waves * lk * UB * 64u * (mt + 1u);  // one unit per wave (octets padded by one row slot), refilled as the wave moves on
+    if (mt >= 32u) {  // the reduction scratch reuses this region: it must hold waves * mt * (nl * cpl) floats (it does: 66 KB against <= 64 KB; kept as a guard)
+      const uint32_t red = (uint32_t)waves * mt * (uint32_t)(nl * cpl) * 4u;
       if (p.act_bytes < red) p.act_bytes = red;
     }
     p.id_bytes = by_id ? p.ups * lk * UB * 64u : 0u;
@@ -1088,7 +1104,7 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
     }
     break;
   }
-  if (dyn_lds_bytes(p, nl, waves, cpl, (int)mt) > (by_id || mt == 32u || nl == 32 ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
+  if (dyn_lds_bytes(p, nl, waves, cpl, (int)mt) > (by_id || mt >= 32u || nl == 32 ? kDynMaxLdsById : kDynMaxLds)) return kDynNotEligible;
   const uint64_t unit_bytes = (uint64_t)lk * UB * BITS * g.n * 4u;
   if ((uint64_t)p.units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31)) return kDynNotEligible;
   if (sets != nullptr) return cpl == 4 ? launch_dyn_multi_si<BITS, 4>(p, stream, rounds) : launch_dyn_multi_si<BITS, 3>(p, stream, rounds);

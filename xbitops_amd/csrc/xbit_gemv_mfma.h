@@ -1,7 +1,9 @@
-// xbit_gemv_mfma.h — the A16Wx GEMV / skinny-GEMM kernel of rounds 1-2 (M = 1..16 per pass) for gfx950, and the launch
-// rules that choose between it and the staged-operand kernel of round 3 (xbit_gemv_dyn.h; launch_bits below).  This kernel
-// still serves the 128-column-tile shapes, 160-tile layers, the measured split plans, fused multi-set launches, few-column
-// layers beyond one row and everything over 128 rows; DESIGN.md section 3.0 has the table.
+// xbit_gemv_mfma.h — the A16Wx GEMV / skinny-GEMM kernel of rounds 1-2 (M = 1..16 per pass) for gfx950, and the interpreter of the launch
+// rule (xbit_gemv_rules.h says WHICH launch serves a call - a table of rows, each with its evidence; launch_by_rules below says HOW).
+// What this kernel still serves, with the measurement that keeps it there, is the table's last rows and DESIGN.md section 3.2:
+// 128-column tiles of very wide 4- / 8-bit layers, 16-column tiles of few-column layers up to 8 rows, 160-tile layers and 2-bit
+// few-column layers at one row, group sizes 32 x odd, split plans whose K ranges exceed the staged-operand kernel's staging, 16-row
+// passes where no 32-row launch applies (few tiles, 2-bit, more than 128 rows).  Measurement variants: xbit_gemv_tuning.h (tuning builds).
 //
 // A workgroup owns a column tile over all of K (or one K range of it: split-K); lanes own whole
 // 32-k blocks of CPL adjacent columns; the packed rows of a lane are loaded a few rows ahead of the
@@ -941,21 +943,26 @@ int act_scored_split(const GemvParams& p, hipStream_t stream, const GemvLaunchOp
   return launch_plan<BITS, UB_>(p, stream, plan, ws);
 }
 
-// Act::DynChunks32: 33..128 rows in launches of 32 (each streams the weights once more), still ahead of 16-row passes and of dequantise +
-// dense GEMM (profiles/r03/linear_crossover_after_chunks_of_32.txt).  Every chunk is checked before the first is launched.
+// Act::DynChunks32: 33..128 rows in launches of up to 64 rows (the 64-row build: four A operands per unpacked B fragment), of 32 where
+// that build does not take the layer (2-bit); each launch streams the weights once more - still ahead of 16-row passes and of dequantise +
+// dense GEMM (profiles/r04/linear_crossover.txt).  Every chunk is checked before the first is launched.
 template <int BITS>
 int act_dyn_chunks(const GemvParams& p, hipStream_t stream, int cpl) {
   GemvParams q = p;
-  return launch_all_or_nothing([&]() -> int {
-    int s = XBIT_OK;
-    for (uint32_t r0 = 0; r0 < p.m && s == XBIT_OK; r0 += 32u) {
-      q.m = p.m - r0 < 32u ? p.m - r0 : 32u;
-      q.a = p.a + (size_t)r0 * p.k;
-      q.out = p.out + (size_t)r0 * p.n;
-      s = launch_gemv_dyn(q, BITS, stream, cpl, 16, true, false, nullptr);
-    }
-    return s;
-  });
+  int st = kGemvDynNotEligible;
+  for (uint32_t chunk = 64u; chunk >= 32u && st == kGemvDynNotEligible; chunk /= 2u) {
+    st = launch_all_or_nothing([&]() -> int {
+      int s = XBIT_OK;
+      for (uint32_t r0 = 0; r0 < p.m && s == XBIT_OK; r0 += chunk) {
+        q.m = p.m - r0 < chunk ? p.m - r0 : chunk;
+        q.a = p.a + (size_t)r0 * p.k;
+        q.out = p.out + (size_t)r0 * p.n;
+        s = launch_gemv_dyn(q, BITS, stream, cpl, 16, true, false, nullptr);
+      }
+      return s;
+    });
+  }
+  return st;
 }
 
 // Act::MfmaDefault: this file's kernel on tiles of the default width.  Weight loads are plain by default: equal to nontemporal when the

@@ -263,7 +263,7 @@ def dequant_gidx(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tens
 def gemv_multi(input_a: torch.Tensor, weights, groupsize: int, bits: int, in_features: int, add_zero_bias: int):
     """Extension (not in the reference): ``[gemv(input_a, qw, sc, qz, ...) for (qw, sc, qz) in weights]`` for
     1..4 weight sets that share ``in_features``, ``bits`` and ``groupsize`` (q/k/v, gate/up) - in ONE
-    kernel launch at batch 1.  Same checks and results as :func:`gemv` per set; returns a list."""
+    kernel launch for up to 16 rows.  Same checks and results as :func:`gemv` per set; returns a list."""
     import ctypes
 
     groupsize, bits, in_features = int(groupsize), int(bits), int(in_features)
