@@ -109,7 +109,7 @@ const char* __asan_default_options() { return "detect_leaks=0"; }  // the librar
 
 // ---- recorders for the launchers of the other translation units ----------------------------------------------------------
 namespace rec {
-int gemv = 0, dequant = 0, gidx = 0, dequant_gidx = 0, multi = 0, dyn_multi = 0;
+int gemv = 0, dequant = 0, gidx = 0, dequant_gidx = 0, dyn_multi = 0;
 int status = XBIT_OK;
 int dyn_multi_status = xbit::kGemvDynNotEligible;
 xbit::GemvParams last;
@@ -136,7 +136,6 @@ int launch_gemv(const GemvParams& p, int, hipStream_t stream, const GemvLaunchOp
 int launch_dequant(const DequantParams&, int, hipStream_t) { return ++rec::dequant, rec::status; }
 int launch_gemv_gidx(const GemvGidxParams&, int, hipStream_t) { return ++rec::gidx, rec::status; }
 int launch_dequant_gidx(const GemvGidxParams&, int, hipStream_t) { return ++rec::dequant_gidx, rec::status; }
-int launch_gemv_multi(const GemvMultiParams&, int, hipStream_t) { return ++rec::multi, rec::status; }
 int launch_gemv_dyn_multi(const GemvParams&, const GemvSets&, int, hipStream_t, int) { return ++rec::dyn_multi, rec::dyn_multi_status; }
 }  // namespace xbit
 
@@ -332,17 +331,17 @@ static void test_multi_and_gidx() {
   EXPECT(xbit_gemv_multi_f16(3, holes, a, qws, scs, qzs, ns, 4, 128, 1, 4096, 1, nullptr) == XBIT_ERR_NULL_POINTER);
   uint32_t odd[3] = {4096, 1023, 1024};
   EXPECT(xbit_gemv_multi_f16(3, outs, a, qws, scs, qzs, odd, 4, 128, 1, 4096, 1, nullptr) == XBIT_ERR_SHAPE);
-  // the staged-operand kernel's fused build is asked first; not eligible -> the round-2 fused build; not eligible -> one launch per set
-  rec::dyn_multi = rec::multi = rec::gemv = 0;
+  // the staged-operand kernel's fused build is asked first; not eligible -> one launch per set
+  rec::dyn_multi = rec::gemv = 0;
   rec::dyn_multi_status = XBIT_OK;
-  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 16, 4096, 1, nullptr) == XBIT_OK && rec::dyn_multi == 1 && rec::multi == 0 && rec::gemv == 0);
+  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 16, 4096, 1, nullptr) == XBIT_OK && rec::dyn_multi == 1 && rec::gemv == 0);
   rec::dyn_multi_status = xbit::kGemvDynNotEligible;
-  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 3, 4096, 1, nullptr) == XBIT_OK && rec::dyn_multi == 2 && rec::multi == 1 && rec::gemv == 0);
-  rec::status = XBIT_ERR_SHAPE;  // "not for the fused build"
-  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 3, 4096, 1, nullptr) == XBIT_ERR_SHAPE && rec::gemv == 1);  // the per-set launches report their own status
+  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 3, 4096, 1, nullptr) == XBIT_OK && rec::dyn_multi == 2 && rec::gemv == 4);
+  rec::status = XBIT_ERR_SHAPE;
+  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 3, 4096, 1, nullptr) == XBIT_ERR_SHAPE && rec::gemv == 5);  // the per-set launches report their own status
   rec::status = XBIT_OK;
-  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 40, 4096, 1, nullptr) == XBIT_OK && rec::gemv == 5);  // 40 rows: one launch per set
-  EXPECT(xbit_gemv_multi_f16(1, outs, a, qws, scs, qzs, ns, 4, 128, 1, 4096, 1, nullptr) == XBIT_OK && rec::gemv == 6);
+  EXPECT(xbit_gemv_multi_f16(4, outs, a, qws, scs, qzs, ns, 4, 128, 40, 4096, 1, nullptr) == XBIT_OK && rec::gemv == 9);  // 40 rows: one launch per set
+  EXPECT(xbit_gemv_multi_f16(1, outs, a, qws, scs, qzs, ns, 4, 128, 1, 4096, 1, nullptr) == XBIT_OK && rec::gemv == 10);
   // act-order entries
   EXPECT(xbit_gemv_gidx_f16(outs[0], a, qws[0], scs[0], qzs[0], gi, 4, 32, 1, 4096, 4096, 1, nullptr) == XBIT_OK && rec::gidx == 1);
   EXPECT(xbit_gemv_gidx_f16(outs[0], a, qws[0], scs[0], qzs[0], nullptr, 4, 32, 1, 4096, 4096, 1, nullptr) == XBIT_ERR_NULL_POINTER);

@@ -453,38 +453,6 @@ int xbit_gemv_multi_f16(int count, void* const* outs, const void* a, const void*
     const int st = xbit::launch_gemv_dyn_multi(p, sets, bits, stream, cpl);
     if (st != xbit::kGemvDynNotEligible) return st;
   }
-  // ... else the round-2 kernel's fused build (up to 4 rows, the fast path's alignment and size limits) ...
-  bool fused = count >= 2 && m <= 4 && (k % 8u == 0) && (groupsize % 32 == 0) && ((uintptr_t)a % 16 == 0);
-  for (int j = 0; j < count && fused; ++j)
-    fused = ((uint64_t)xbit::packed_rows(k, bits) * ns[j] * 4u < (1ull << 31)) && ((uintptr_t)qweights[j] % 4 == 0);
-  if (fused) {
-    xbit::GemvMultiParams p = {};
-    p.a = static_cast<const uint16_t*>(a);
-    p.m = m;
-    p.k = k;
-    p.groupsize = (uint32_t)groupsize;
-    p.kw = xbit::packed_rows(k, bits);
-    p.groups = (k + (uint32_t)groupsize - 1) / (uint32_t)groupsize;
-    p.bias = add_zero_bias;
-    p.splits = 1;
-    p.multi_count = (uint32_t)count;
-    for (int j = 0; j < count; ++j) {
-      p.multi_n[j] = ns[j];
-      p.multi_zw[j] = xbit::packed_rows(ns[j], bits);
-      p.multi_qweight[j] = static_cast<const uint32_t*>(qweights[j]);
-      p.multi_scales[j] = static_cast<const uint16_t*>(scales[j]);
-      p.multi_qzeros[j] = static_cast<const uint32_t*>(qzeros[j]);
-      p.multi_out[j] = static_cast<uint16_t*>(outs[j]);
-    }
-    p.out = p.multi_out[0];
-    p.qweight = p.multi_qweight[0];
-    p.scales = p.multi_scales[0];
-    p.qzeros = p.multi_qzeros[0];
-    p.n = ns[0];
-    p.zw = xbit::packed_rows(ns[0], bits);
-    const int st = xbit::launch_gemv_multi(p, bits, stream);
-    if (st != XBIT_ERR_SHAPE) return st;
-  }
   // ... otherwise one launch per weight set
   for (int j = 0; j < count; ++j) {
     const int st = xbit_gemv_f16(outs[j], a, qweights[j], scales[j], qzeros[j], bits, groupsize, m, k, ns[j], add_zero_bias, hip_stream);

@@ -130,14 +130,10 @@ struct RowLoad {
 //        partial sums meet in per-element 64-bit fixed-point accumulators (one returning atomic
 //        per element and workgroup, see the epilogue).  For few column tiles and long K
 //        (down-projections), where whole-K tiles leave CUs idle.
-//   MULTI  fused launch: the grid covers the column tiles of up to 4 weight sets that share K, the
-//        bit-width, the group size and the activation (q/k/v, gate/up); a workgroup looks up its set.
-//        A separate template (gemv_mfma_multi_kernel below shares this body through the MULTI flag
-//        and takes the larger argument block), so the plain kernels are compiled exactly as before.
-template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0, bool SPLIT = false, bool MULTI = false>
-__global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::conditional_t<MULTI, GemvMultiParams, GemvParams> p) {
+//        (Fused launches over several weight sets: the MULTI builds of the staged-operand kernel, xbit_gemv_dyn.h, since round 4.)
+template <int BITS, int UB, int CPL, int NL, int NW, int MT, bool NT, bool GUARD, int ABLATE = 0, int LA = 0, bool SPLIT = false>
+__global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const GemvParams p) {
   static_assert(!SPLIT || GUARD, "split-K launches use the guarded build");
-  static_assert(!MULTI || (GUARD && !SPLIT && ABLATE == 0), "fused launches use the guarded, unsplit build");
   static_assert(CPL >= 2 && CPL <= 4, "columns per lane");
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
   constexpr bool WAITFIRST = (ABLATE & 131072) != 0;
@@ -189,22 +185,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_mfma_kernel(const std::condition
   const uint32_t T = (uint32_t)(LK * nwaves);  // k-batches per workgroup sweep
   const uint32_t split = SPLIT ? blockIdx.x % p.splits : 0u;
   const uint32_t tile_g = SPLIT ? blockIdx.x / p.splits : xcd_tile(blockIdx.x, p.tiles);  // tile of the whole grid
-  // this workgroup's weight set: the only one (p.n, p.qweight, ...) or, fused, set j of p.multi_*
-  uint32_t tile = tile_g, n_ = p.n, zw_ = p.zw;
-  const uint32_t* qweight_ = p.qweight;
-  const uint16_t* scales_ = p.scales;
-  const uint32_t* qzeros_ = p.qzeros;
-  uint16_t* out_ = p.out;
-  if constexpr (MULTI) {
-    const uint32_t j = (tile_g >= p.multi_tile_end[0] ? 1u : 0u) + (tile_g >= p.multi_tile_end[1] ? 1u : 0u) + (tile_g >= p.multi_tile_end[2] ? 1u : 0u);
-    tile = tile_g - (j ? p.multi_tile_end[j - 1] : 0u);
-    n_ = p.multi_n[j];
-    zw_ = p.multi_zw[j];
-    qweight_ = p.multi_qweight[j];
-    scales_ = p.multi_scales[j];
-    qzeros_ = p.multi_qzeros[j];
-    out_ = p.multi_out[j];
-  }
+  const uint32_t tile = tile_g, n_ = p.n, zw_ = p.zw;
+  const uint32_t* const qweight_ = p.qweight;
+  const uint16_t* const scales_ = p.scales;
+  const uint32_t* const qzeros_ = p.qzeros;
+  uint16_t* const out_ = p.out;
   const uint32_t b_begin = SPLIT ? split * p.bps : 0u;
   const uint32_t b_end = SPLIT ? (b_begin + p.bps < p.batches ? b_begin + p.bps : p.batches) : p.batches;
   const uint32_t k_end = SPLIT ? (b_end * (uint32_t)(UB * 32) < p.k ? b_end * (uint32_t)(UB * 32) : p.k) : p.k;  // activations beyond: 0
@@ -788,54 +773,6 @@ int launch_cpl(const GemvParams& p, hipStream_t stream, int cpl, uint32_t wave_c
     case 3: return launch_rows<BITS, UB, 3, 16, NT>(p, stream, wave_cap);
     default: return launch_rows<BITS, UB, 2, 16, NT>(p, stream, wave_cap);
   }
-}
-
-// fused launch (MULTI): up to kMaxMulti weight sets, M <= 4, 16-lane tiles of 16*CPL columns
-template <int BITS, int UB, int CPL, int NW, int MT>
-int launch_multi_mt(GemvMultiParams p, hipStream_t stream, uint32_t waves) {
-  constexpr uint32_t CN = 16 * CPL;
-  uint32_t end = 0;
-  for (uint32_t j = 0; j < (uint32_t)kMaxMulti; ++j) {
-    if (j < p.multi_count) end += (p.multi_n[j] + CN - 1) / CN;
-    p.multi_tile_end[j] = j < p.multi_count ? end : 0xFFFFFFFFu;
-  }
-  p.tiles = end;
-  p.batches = ((p.k + 31) / 32 + UB - 1) / UB;
-  dim3 grid(p.tiles, (p.m + MT - 1) / MT), block(64 * (waves < (uint32_t)NW ? waves : (uint32_t)NW));
-  return launch(gemv_mfma_kernel<BITS, UB, CPL, 16, NW, MT, false, true, 0, lookahead_for<BITS>(), false, true>, grid, block, stream, p);
-}
-
-template <int BITS, int UB, int CPL>
-int launch_multi_one(const GemvMultiParams& p, hipStream_t stream, uint32_t batches, uint32_t tiles) {
-  if (p.m == 1) {
-    constexpr bool fit = fits_16_waves<BITS, CPL, 16, 1>();
-    const uint32_t waves = sweep_waves(batches, 4, (fit && tiles <= 240u) ? 16u : 8u);
-    if constexpr (fit) {
-      if (waves > 8u) return launch_multi_mt<BITS, UB, CPL, 16, 1>(p, stream, waves);
-    }
-    return launch_multi_mt<BITS, UB, CPL, 8, 1>(p, stream, waves);
-  }
-  constexpr bool fit = fits_16_waves<BITS, CPL, 16, 4>();
-  const uint32_t waves = sweep_waves(batches, 4, (fit && tiles <= 240u) ? 16u : 8u);
-  if constexpr (fit) {
-    if (waves > 8u) return launch_multi_mt<BITS, UB, CPL, 16, 4>(p, stream, waves);
-  }
-  return launch_multi_mt<BITS, UB, CPL, 8, 4>(p, stream, waves);
-}
-
-template <int BITS>
-int launch_multi_bits(const GemvMultiParams& p, hipStream_t stream) {
-  constexpr int UBMAX = max_ub<BITS>();
-  if (p.m > 4 || p.groupsize % (32u * UBMAX) != 0) return XBIT_ERR_SHAPE;  // caller launches one by one
-  uint32_t total_n = 0;
-  for (uint32_t j = 0; j < p.multi_count; ++j) total_n += p.multi_n[j];
-  const int cpl = pick_cpl(total_n);  // the width the concatenated layer would get
-  uint32_t tiles = 0;
-  for (uint32_t j = 0; j < p.multi_count; ++j) tiles += (p.multi_n[j] + 16u * cpl - 1) / (16u * cpl);
-  const uint32_t batches = ((p.k + 31) / 32 + UBMAX - 1) / UBMAX;
-  if (cpl == 4) return launch_multi_one<BITS, UBMAX, 4>(p, stream, batches, tiles);
-  if (cpl == 3) return launch_multi_one<BITS, UBMAX, 3>(p, stream, batches, tiles);
-  return launch_multi_one<BITS, UBMAX, 2>(p, stream, batches, tiles);
 }
 
 // ---- the launch rule: xbit_gemv_rules.h says WHICH launch, the functions below HOW --------------------------------------------------

@@ -13,13 +13,6 @@ int launch_gemv_mfma_b6(const GemvParams& p, hipStream_t stream, const GemvLaunc
 int launch_gemv_mfma_b7(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
 int launch_gemv_mfma_b8(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts);
 
-int launch_gemv_multi_b2(const GemvMultiParams& p, hipStream_t stream);
-int launch_gemv_multi_b3(const GemvMultiParams& p, hipStream_t stream);
-int launch_gemv_multi_b4(const GemvMultiParams& p, hipStream_t stream);
-int launch_gemv_multi_b5(const GemvMultiParams& p, hipStream_t stream);
-int launch_gemv_multi_b6(const GemvMultiParams& p, hipStream_t stream);
-int launch_gemv_multi_b7(const GemvMultiParams& p, hipStream_t stream);
-int launch_gemv_multi_b8(const GemvMultiParams& p, hipStream_t stream);
 
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts) {
   switch (bits) {
@@ -30,19 +23,6 @@ int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const Ge
     case 6: return launch_gemv_mfma_b6(p, stream, opts);
     case 7: return launch_gemv_mfma_b7(p, stream, opts);
     case 8: return launch_gemv_mfma_b8(p, stream, opts);
-    default: return XBIT_ERR_BITS;
-  }
-}
-
-int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream) {
-  switch (bits) {
-    case 2: return launch_gemv_multi_b2(p, stream);
-    case 3: return launch_gemv_multi_b3(p, stream);
-    case 4: return launch_gemv_multi_b4(p, stream);
-    case 5: return launch_gemv_multi_b5(p, stream);
-    case 6: return launch_gemv_multi_b6(p, stream);
-    case 7: return launch_gemv_multi_b7(p, stream);
-    case 8: return launch_gemv_multi_b8(p, stream);
     default: return XBIT_ERR_BITS;
   }
 }

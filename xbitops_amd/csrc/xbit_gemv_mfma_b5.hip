@@ -4,6 +4,5 @@
 namespace xbit {
 
 int launch_gemv_mfma_b5(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts) { return launch_bits<5>(p, stream, opts); }
-int launch_gemv_multi_b5(const GemvMultiParams& p, hipStream_t stream) { return launch_multi_bits<5>(p, stream); }
 
 }  // namespace xbit

@@ -4,6 +4,5 @@
 namespace xbit {
 
 int launch_gemv_mfma_b7(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts) { return launch_bits<7>(p, stream, opts); }
-int launch_gemv_multi_b7(const GemvMultiParams& p, hipStream_t stream) { return launch_multi_bits<7>(p, stream); }
 
 }  // namespace xbit

@@ -4,6 +4,5 @@
 namespace xbit {
 
 int launch_gemv_mfma_b8(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& opts) { return launch_bits<8>(p, stream, opts); }
-int launch_gemv_multi_b8(const GemvMultiParams& p, hipStream_t stream) { return launch_multi_bits<8>(p, stream); }
 
 }  // namespace xbit

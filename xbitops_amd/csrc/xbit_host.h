@@ -41,19 +41,6 @@ struct GemvParams {
   unsigned long long* acc;  // [grid.y][tiles][MT * CN], zero between launches (the last arriver resets its slot)
 };
 
-// Fused launches (MULTI builds of the kernel): several weight sets with the same K / bits / group size
-// and ONE activation (q/k/v, gate/up) share a grid; tile t belongs to set j with
-// multi_tile_end[j-1] <= t < multi_tile_end[j].  A separate kernel-argument type: the plain kernels keep
-// their argument block (and their code) unchanged.
-struct GemvMultiParams : GemvParams {
-  uint32_t multi_count;
-  uint32_t multi_tile_end[kMaxMulti], multi_n[kMaxMulti], multi_zw[kMaxMulti];
-  const uint32_t* multi_qweight[kMaxMulti];
-  const uint16_t* multi_scales[kMaxMulti];
-  const uint32_t* multi_qzeros[kMaxMulti];
-  uint16_t* multi_out[kMaxMulti];
-};
-
 // Fused launches of the staged-operand kernel (xbit_gemv_dyn.h, MULTI builds): the weight sets of one launch.  Passed to the
 // kernel by value; tile t of the grid belongs to set j with tile_end[j-1] <= t < tile_end[j] (filled in by the launcher,
 // which knows the tile width; unused entries: tile_end = 0xFFFFFFFF).
@@ -158,8 +145,6 @@ int launch_dequant(const DequantParams& p, int bits, hipStream_t stream);
 int launch_dequant_by_id(const DequantParams& p, const int32_t* g_idx, int bits, hipStream_t stream);
 int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);          // dispatcher (xbit_gemv.hip)
 int launch_gemv_mfma(const GemvParams& p, int bits, hipStream_t stream, const GemvLaunchOpts& opts);     // xbit_gemv_mfma.hip
-// fused launch over p.multi_* (M = 1); XBIT_ERR_SHAPE when the shape is not eligible (caller then launches one by one)
-int launch_gemv_multi(const GemvMultiParams& p, int bits, hipStream_t stream);
 // One activation row through the staged-operand kernel (xbit_gemv_dyn.h): tiles of 16 * cpl columns (nl = 16) or 16 columns
 // (nl = 8, cpl = 2).  Returns kGemvDynNotEligible when the shape is not for that kernel (the caller launches another).
 constexpr int kGemvDynNotEligible = 1 << 30;
