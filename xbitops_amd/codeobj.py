@@ -12,8 +12,8 @@ import re
 import struct
 
 _MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-_GEMV = re.compile(r"gemv_mfma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E")
-GEMV_FIELDS = ("bits", "ub", "cpl", "nl", "nw", "mt", "nt", "guard", "ablate", "la", "split", "multi")
+_GEMV = re.compile(r"gemv_mfma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)E")
+GEMV_FIELDS = ("bits", "ub", "cpl", "nl", "nw", "mt", "nt", "guard", "ablate", "la", "split")
 
 
 def _notes(elf: bytes):
