@@ -246,19 +246,32 @@ def offline_profile(workload_key: str, this_lib_sha: str):
     return best
 
 
-def floor_tile_shape(n: int, bits: int, batch: int):
-    """The column tiles the library's launch rule walks for an N-column layer at one row (for the pure-read floor): lane-map
-    width and columns owned per tile.  Mirrors the rule in xbit_gemv_mfma.h / xbit_host.h (pick_cpl, fill_tcols)."""
-    t128 = -(-n // 128)
-    if bits in (4, 8) and n >= 21504 and 3 * t128 >= 2 * (-(-t128 // 256) * 256) and batch <= 8:
-        return 128, 0  # 128-column tiles (kWide of xbit_gemv_rules.h)
-    best, best_eff = 32, -1.0
-    for cpl in (2, 3, 4):
-        tiles = -(-n // (16 * cpl))
-        eff = n / (16.0 * cpl) / (-(-tiles // 256) * 256)
-        if eff >= best_eff - 1e-9:
-            best, best_eff = 16 * cpl, eff
-    return best, 0
+def floor_tile_shape(lib, bits: int, group: int, batch: int, k: int, n: int):
+    """The column tiles the library's launch for this call walks, read back from its dry run (xbit_dry_run_begin / _end: the
+    launch rule runs, nothing is issued): lane-map width for the pure-read floor, or None when the launch is not one grid of
+    whole-K column tiles of 32 / 48 / 64 / 128 columns (split-K plans, 16-column tiles, several launches) - the floor kernels
+    have no such pattern, and a floor that does not mirror the launch would say nothing about it."""
+    import re
+
+    from xbitops_amd import _lib
+
+    fake = 0x10000000  # never followed in a dry run
+
+    def call():
+        _lib.check(lib.xbit_gemv_f16(fake, fake, fake, fake, fake, bits, group, batch, k, n, 1, None), "xbit_gemv_f16 (dry run)")
+
+    recs = _lib.dry_run(lib, call)
+    if len(recs) != 1:
+        return None
+    m = re.search(r"gemv_(dyn|mfma)_kernel<([^>]*)>", recs[0]["kernel"])
+    if not m:
+        return None
+    a = [x.strip() for x in m.group(2).split(",")]
+    cpl, nl = int(a[2]), int(a[3])
+    split = a[10] == "true"  # SPLIT is the 11th template argument of both kernels
+    if split or nl not in (16, 32) or (nl == 32 and cpl != 4):
+        return None
+    return nl * cpl
 
 
 def main(argv=None):
@@ -579,7 +592,7 @@ def main(argv=None):
             tun, read_floor = None, {"note": "measurement build unavailable (%s)" % str(exc).splitlines()[0][:120]}
         if tun is not None:
             kw_rows = qws[0].shape[0]
-            pattern, tcols = floor_tile_shape(n_local, bits, batch)
+            pattern, tcols = floor_tile_shape(lib if gemv_opts is None else _lib.load(), bits, group, batch, k_in, n_local), 0
             sp = stream.cuda_stream
 
             def floor_fn(pat, tc):
@@ -589,13 +602,15 @@ def main(argv=None):
                         raise RuntimeError("xbit_tuning_read_floor -> %d" % st)
                 return fn
 
-            floor_fn(0, 0)(0), floor_fn(pattern, tcols)(0)
+            floor_fn(0, 0)(0)
+            if pattern:
+                floor_fn(pattern, tcols)(0)
             torch.cuda.synchronize()
             read_floor = {
                 "flat": round(chain_period_us(floor_fn(0, 0)), 3),
-                "tiles": round(chain_period_us(floor_fn(pattern, tcols)), 3),
+                "tiles": round(chain_period_us(floor_fn(pattern, tcols)), 3) if pattern else None,  # None: the launch is not one grid of whole-K 32..128-column tiles (split-K, 16-column tiles)
                 "kernel_chain_us": round(chain_period_us(lambda i: kernel_step(i, sp)), 3),
-                "tile_lane_map_columns": pattern, "tile_columns": tcols or pattern,
+                "tile_lane_map_columns": pattern, "tile_columns": pattern,
                 "bytes_read": int(qws[0].numel() * 4),
                 "what": "period of 200 back-to-back launches behind a blocker (median of 3), cold weight copies: pure read of the packed rows - flat 16-byte stream / the GEMV's "
                         "column tiles, all loads up front, no arithmetic - and the GEMV itself by the same clock; scales, zero-points, activations and outputs are not read by the floors",
