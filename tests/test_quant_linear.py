@@ -156,3 +156,17 @@ def test_act_order_state_dict_round_trip():
     bad["g_idx"] = bad["g_idx"][:-1]
     with pytest.raises(RuntimeError):
         QuantLinear(k, n, bits, g, 1).load_state_dict(bad)
+
+
+def test_fused_rows_limit_is_shape_aware():
+    """layers the multi-row builds do not take (odd group sizes, group 32 at 2 bits) leave the fused path at 32 rows
+    instead of 128; general act-order layers whose group table does not fit the by-id builds leave it at 4."""
+    from xbitops_amd import linear
+
+    assert linear.fused_rows_limit(4096, 128, 4) == linear.GEMV_MAX_ROWS == 128
+    assert linear.fused_rows_limit(4096, 32, 4) == 128 and linear.fused_rows_limit(4096, 64, 2) == 128 and linear.fused_rows_limit(11008, 256, 8) == 128
+    assert linear.fused_rows_limit(4096, 48, 4) == 32      # odd group size: by-id builds, 32 rows per launch
+    assert linear.fused_rows_limit(7167, 128, 4) == 128    # ragged K: the same builds, masked tail (round 4)
+    assert linear.fused_rows_limit(4096, 32, 2) == 32      # 2-bit needs groups of 64 and more
+    assert linear.fused_rows_limit(4096, 96, 4) == 32      # 32 x odd
+    assert linear.GIDX_GEMV_MAX_ROWS_OTHER < linear.GIDX_GEMV_MAX_ROWS

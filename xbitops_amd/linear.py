@@ -19,10 +19,11 @@ from . import ops, packing
 # 128.  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM), so the fused one keeps
 # the lead up to about 128 rows.
 GEMV_MAX_ROWS = 128
-# ... for layers the multi-row builds take: in_features % 8 == 0 and a group size that is a power-of-two multiple of 32 (64 at
-# 2 bits).  Other layers get 16 rows per launch at best (odd group sizes: the by-id builds) or the column kernel's 4-row passes
-# (ragged K), so beyond 16 rows they go to dequantise + dense GEMM as in round 2.
-GEMV_MAX_ROWS_OTHER = 16
+# ... for layers the multi-row builds take: a group size that is a power-of-two multiple of 32 (64 at 2 bits), ANY in_features (round 4:
+# a row length that is no multiple of 8 is masked where it is staged; 7166x4096 w4 at 32 rows 17.2 us).  Other group sizes (48, 80, 96 ...)
+# run the by-id builds, 32 rows per launch (4096x4096 w4 at group 48: 16.6 us at 24 rows, 29.6 at 40 - profiles/r04/sweep_ragged_shapes.txt),
+# so beyond 32 rows they go to dequantise + dense GEMM.
+GEMV_MAX_ROWS_OTHER = 32
 # General act-order layers (any g_idx): the library takes rows sixteen to a launch (4096x11008 w4: 10.4 us at one row, 11.9
 # at sixteen - profiles/r03/gidx_rows_8_16.txt); three launches (36 us) still beat the act-order dequant (25 us) plus the
 # dense GEMM (23 us and more), four do not.
@@ -37,7 +38,7 @@ def fused_rows_limit(in_features: int, groupsize: int, bits: int) -> int:
     """Rows up to which a contiguous-group layer of this shape should take the fused kernel rather than dequantise + dense GEMM."""
     unit = 64 if bits == 2 else 32
     q = groupsize // unit
-    regular = in_features % 8 == 0 and groupsize % unit == 0 and q >= 1 and (q & (q - 1)) == 0
+    regular = groupsize % unit == 0 and q >= 1 and (q & (q - 1)) == 0
     return GEMV_MAX_ROWS if regular else GEMV_MAX_ROWS_OTHER
 
 
