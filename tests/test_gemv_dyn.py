@@ -354,11 +354,23 @@ def test_odd_group_sizes_seventeen_to_forty_rows(bits, cuda_device):
 
 @pytest.mark.parametrize("bits", range(2, 9))
 def test_thirty_three_to_one_twenty_eight_rows(bits, cuda_device):
-    """33..64 rows: the 64-row build (four A operands per unpacked B fragment, four waves per workgroup; from 3 bits up), 65..128: two
-    launches of it; ragged K and few-tile layers included."""
+    """33..128 rows: one launch of the 32-row build, the blocks of 32 rows in grid.y (from 3 bits up; 2-bit: 16-row passes); ragged K and
+    few-tile layers included."""
     lib = _lib.load()
     for k, n, g, m in [(4096, 11008, 128, 64), (4096, 11008, 128, 33), (2048, 9216, 64, 48), (8192, 12288, 128, 64), (4096, 10000, 128, 100), (1024, 9300, 128, 128),
                        (4098, 9216, 128, 40), (4097, 1024, 128, 57)]:
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 29 + k + m)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m), k=k)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 5, 8])
+def test_rows_in_grid_y(bits, cuda_device):
+    """More than 32 rows as blocks of 32 rows in grid.y of ONE launch of the 32-row build (production: 33..128 rows; variant 348: any count up to 256),
+    ragged K and a ragged last block included."""
+    lib, tun = _lib.load(), _lib.load_tuning()
+    for k, n, g, m, variant in [(4096, 11008, 128, 128, -1), (2048, 9216, 64, 65, -1), (4098, 9300, 128, 100, -1), (1024, 9216, 128, 40, 348), (4096, 3000, 128, 200, 348),
+                                (4097, 9216, 128, 97, 348)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 31 + k + m)
+        y = _run_m(tun if variant > 0 else lib, p, 1, cuda_device, variant)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, k, n, g, m, variant), k=k)

@@ -110,9 +110,10 @@ def test_launch_rules_grid_is_as_recorded(native_lib):
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
-def test_thirty_three_to_sixty_four_rows_are_one_launch(native_lib):
-    for m, launches in ((33, 1), (64, 1), (65, 2), (128, 2)):
-        recs = plan(native_lib, 4, m, 4096, 11008)
-        assert len(recs) == launches and all("gemv_dyn_kernel<4, 1, 3, 16, 4," in r["kernel"] or m in (65,) for r in recs), recs  # the 64-row build: four waves
-    recs = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit has no 32- / 64-row build: 16-row passes of the round-2 kernel
+def test_thirty_three_to_one_twenty_eight_rows_are_one_launch(native_lib):
+    """33..128 rows on many tiles: ONE launch of the 32-row build with the blocks of 32 rows in grid.y."""
+    for m, blocks in ((33, 2), (64, 2), (65, 3), (128, 4)):
+        (r,) = plan(native_lib, 4, m, 4096, 11008)
+        assert "gemv_dyn_kernel<4, 1, 3, 16, 8, true, 2, 4, 4, 0, false, false, 32, false>" in r["kernel"] and r["grid"] == (230, blocks, 1), (m, r)
+    recs = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit has no 32-row build: 16-row passes of the round-2 kernel
     assert "gemv_mfma_kernel<2," in recs[0]["kernel"], recs

@@ -391,11 +391,11 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
   // k / groupsize), activations and scales on any halfword - up to 128 rows.  What is left for the column kernel below: more rows
   // than that, tensors of 2 GiB and more, staged operands beyond LDS (profiles/r04/sweep_ragged_shapes.txt).
   if (p.m <= 128u && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
-    // rows in launches of up to 64 (each streams the weights once more) - of 32 or 16 where the larger build does not take the layer;
+    // ... by-id layers (act-order-like: odd group sizes) and 2-bit: rows in launches of 32, of 16 where the 32-row build does not take the layer;
     // every chunk is checked before the first goes out
     GemvParams q = p;
-    int st = kGemvDynNotEligible;
-    for (uint32_t chunk = 64u; chunk >= 16u && st == kGemvDynNotEligible; chunk /= 2u) {
+    int st = p.m > 32u ? launch_gemv_dyn(p, bits, stream, pick_cpl(p.n), 16, true, false, nullptr) : kGemvDynNotEligible;  // 33..128 rows: one launch, blocks of 32 rows in grid.y
+    for (uint32_t chunk = 32u; chunk >= 16u && st == kGemvDynNotEligible; chunk /= 2u) {
       st = launch_all_or_nothing([&]() -> int {
         int s = kGemvDynNotEligible;
         for (uint32_t r0 = 0; r0 < p.m; r0 += chunk) {

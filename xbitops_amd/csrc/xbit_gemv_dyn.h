@@ -113,6 +113,7 @@ struct DynParams {
   const GemvSets* sets;     // host side only: the weight sets of a fused launch (MULTI builds), else null
   uint32_t mt;              // host side only: rows of the build that takes this launch (1, 4, 8, 16, 32; >= m)
   uint32_t wide_probe;      // host side only, tuning builds: which measurement build of the 128-column tiles (0: the production one)
+  uint32_t row_blocks;      // host side only: grid.y (blocks of 32 rows of the 32-row build), else 1
 };
 
 // Template parameters
@@ -139,9 +140,10 @@ struct DynParams {
 //          (16-bit) are staged in LDS next to the activations, the table holds EVERY group, and each weight pair looks
 //          its two (scale, -zero*scale) entries up from its own rows' ids - 8 LDS reads and 2 v_perm per pair and
 //          column more than the contiguous build, no change to the weight stream.
-//   MT     activation rows per launch (1, 4, 8, 16, 32 or 64; 32 / 64: two / four A operands - rows 0-15, 16-31, ... - per unpacked B
-//          fragment, so every weight is unpacked once for all the rows; the 64-row build runs four waves per workgroup: a wave's
-//          activation image of one unit is 16.6 KB there): the MFMA's A operand carries row (lane & 15) % MT, the staged
+//   MT     activation rows per workgroup (1, 4, 8, 16 or 32; 32: two A operands - rows 0-15 and 16-31 - per unpacked B fragment, so
+//          every weight is unpacked once for all 32 rows; more than 32 rows: blocks of 32 rows in grid.y of one launch.  A 64-row
+//          build - four A operands, four waves per workgroup - measured the same as two row blocks, profiles/r04/sweep_rows_in_grid_y.txt,
+//          and was dropped: above 32 rows a launch is bound by its activation stream, 0.31 us per row on 4096x11008, not by its weights): the MFMA's A operand carries row (lane & 15) % MT, the staged
 //          activation image holds MT rows per octet, D rows 0..MT-1 are the results (the rest are copies).  1 and 4: the
 //          staging waves put the whole K range of every row into LDS up front.  8 and 16 (2 / 4 KB of activations per unit -
 //          the whole K range would be 64 / 128 KB at K = 4096): every wave fetches the activations of ITS next unit itself,
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(64 * NW)
                     const GemvSets sets) {
   // scalar arguments in order of urgency (not one struct), so that a build with kernel-argument preload could hand the
   // first ones over in SGPRs (measured: profiles/r03/lab_5_kernarg_preload.txt)
-  DynParams p = {qweight, n, tiles, kw, units, tcols, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u, nullptr, (uint32_t)MT, 0u};
+  DynParams p = {qweight, n, tiles, kw, units, tcols, a, scales, qzeros, out, k, groups, zw, bias, m, tab_groups, gshift, act_bytes, splits, ups, split_acc, g_idx, trace, GIDX, 0u, nullptr, (uint32_t)MT, 0u, 1u};
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int LK = 64 / NL;   // k-slots per wave
@@ -177,10 +179,17 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(NL == 32 || NL == 16 || NL == 8, "lanes along N");
   static_assert(!WIDE || (MT <= 4 && !GIDX), "128-column tiles: up to four rows, contiguous groups");
   static_assert(STW >= 1 && STW <= NW, "staging waves");
+  if constexpr (MT == 32 && !SPLIT) {  // more than 32 rows in ONE launch: grid.y counts blocks of 32 rows; the row blocks of a column tile run side by side
+                                     // on the chip and share the tile's packed rows through L2 (the weights leave HBM once)
+    const uint32_t rb = blockIdx.y;
+    p.a += (size_t)rb * 32u * p.k;
+    p.out += (size_t)rb * 32u * p.n;
+    p.m = p.m - rb * 32u < 32u ? p.m - rb * 32u : 32u;
+  }
   static_assert(!GIDX || !SPLIT, "act-order launches keep K whole");
   static_assert(!MULTI || (!GIDX && !SPLIT && FLAGS == 0), "fused launches: contiguous groups, whole K");
-  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32 || MT == 64, "rows per launch");
-  constexpr int RG = MT > 16 ? MT / 16 : 1;  // row groups of 16: one A operand each per unpacked B fragment (32 rows: 2, 64 rows: 4)
+  static_assert(MT == 1 || MT == 4 || MT == 8 || MT == 16 || MT == 32, "rows per launch");
+  constexpr int RG = MT > 16 ? MT / 16 : 1;  // row groups of 16: one A operand each per unpacked B fragment (32 rows: 2)
   constexpr bool WAVEACT = MT >= 8;  // activations per wave and unit, pipelined (see MT)
   static_assert(!WAVEACT || (NL == 16 && FLAGS == 0), "8 / 16 / 32 rows: tiles of 16 lanes");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -834,7 +843,6 @@ inline size_t dyn_lds_bytes(const DynParams& p, int nl, int nw, int cpl, int mt)
 
 constexpr int kDynNotEligible = kGemvDynNotEligible;  // not a status: "this shape is not for this kernel", the caller launches another
 constexpr int kDynWaves = 8, kDynStagers = 4, kDynLookahead = 4;
-constexpr int kDynWaves64 = 4;  // the 64-row build: 4 waves x 16.6 KB of activations per unit
 constexpr size_t kDynMaxLds = 96u << 10;  // larger staged operands (K beyond ~24 K at g128) stay with xbit_gemv_mfma.h
 constexpr size_t kDynMaxLdsById = 156u << 10;  // act-order / odd group sizes: two table rows of 256 B per group (K = 4096 at group 16: 128 KB of them)
 
@@ -854,7 +862,7 @@ int launch_dyn_one(const DynParams& p, hipStream_t stream) {
   if (MULTI && p.sets != nullptr) sets = *p.sets;
   void* args[] = {&q.qweight, &q.n, &q.tiles, &q.kw, &q.units, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias, &q.m,
                   &q.tab_groups, &q.gshift, &q.act_bytes, &q.splits, &q.ups, &q.acc, &q.g_idx, &q.trace, &q.tcols, &sets};
-  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u)), dim3(64 * NW),
+  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(p.tiles * (SPLIT ? p.splits : 1u), (MT == 32 && !SPLIT && p.row_blocks > 1u) ? p.row_blocks : 1u), dim3(64 * NW),
                             dyn_lds_bytes(p, NL, NW, CPL, MT), stream, args);
 }
 
@@ -916,7 +924,6 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
 #endif
   if (p.by_id) {  // act-order: 48-column tiles; 1 or up to 4 rows: K up to 4096 (2 rounds) or 8192 (4 rounds); 5..16 rows: any K
     if constexpr (NL == 16 && CPL == 3) {
-      if (p.mt > 32u) return kDynNotEligible;  // by id: up to 32 rows per launch
       if (p.mt > 16u) {  // 2-bit (2 k-blocks per unit) does not fit the 32-row builds into 256 registers: not compiled, 16 rows per launch there
         if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, true, 32>(p, stream);
         return kDynNotEligible;
@@ -939,18 +946,14 @@ int launch_dyn_si(const DynParams& p, hipStream_t stream, uint32_t rounds, bool 
         if constexpr (CPL == 4) {
           if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 8>(p, stream);
           if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 16>(p, stream);
-          if (p.mt > 32u) return kDynNotEligible;
           if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, true, false, 32>(p, stream);  // 17..32 rows (round 4)
         }
         return kDynNotEligible;
       }
       if (p.mt <= 8u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 8>(p, stream);  // table rounds beyond 2: staged in a loop
       if (p.mt <= 16u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 16>(p, stream);
-      if constexpr (dyn_ub<BITS>() == 1) {
-        if (p.mt > 32u) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 64, kDynWaves64>(p, stream);  // 33..64 rows: four waves per workgroup
-        return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);
-      }
-      return kDynNotEligible;  // 2-bit: no 32- / 64-row build (they would spill)
+      if constexpr (dyn_ub<BITS>() == 1) return launch_dyn_one<BITS, CPL, NL, NT, 2, 0, false, false, 32>(p, stream);  // (p.row_blocks of them in grid.y)
+      return kDynNotEligible;  // 2-bit: no 32-row build (it would spill)
     }
     return kDynNotEligible;
   }
@@ -993,7 +996,7 @@ template <int BITS>
 int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bool nt, bool stamped, uint64_t* trace, uint32_t splits = 1,
                     unsigned long long* acc = nullptr, const int32_t* g_idx = nullptr, uint32_t tcols = 0, const GemvSets* sets = nullptr) {
   constexpr int UB = dyn_ub<BITS>();
-  if (g.m < 1u || g.m > 64u || (g.m > 1u && stamped)) return kDynNotEligible;  // (a row length that is no multiple of 8 is masked where it is staged)
+  if (g.m < 1u || g.m > 256u || (g.m > 1u && stamped)) return kDynNotEligible;  // (a row length that is no multiple of 8 is masked where it is staged)
   if (g.m > 4u && nl != 16) return kDynNotEligible;                              // 5..32 rows: tiles of 16 lanes
   if (sets != nullptr && (nl != 16 || (cpl != 3 && cpl != 4) || g.m > 16u || g_idx != nullptr || g.groupsize % 32u != 0u || splits > 1u || stamped || tcols != 0u ||
                           sets->count < 1u || sets->count > (uint32_t)kMaxMulti))
@@ -1070,9 +1073,13 @@ int launch_dyn_bits(const GemvParams& g, hipStream_t stream, int cpl, int nl, bo
   // build (act-order: 4 = K 8192; contiguous: 8 / 4); a longer K takes the 8-row build instead, whose waves fetch their
   // activations unit by unit and whose table is staged in a loop - rows beyond m read zeros.  (Round 3 fell to the
   // round-2 kernels there: an act-order down-projection with K = 11008 at batch 1.)
-  uint32_t mt = g.m > 32u ? 64u : (g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u))));
-  if (mt == 64u && (by_id || splits > 1u || sets != nullptr || nl != 16)) return kDynNotEligible;  // 33..64 rows: contiguous groups, whole K, one weight set
-  const int waves = nl == 32 ? kDynWideWaves : (mt == 64u ? kDynWaves64 : kDynWaves);
+  uint32_t mt = g.m > 16u ? 32u : (g.m > 8u ? 16u : (g.m > 4u ? 8u : (g.m > 1u ? 4u : 1u)));
+  p.row_blocks = 1u;
+  if (g.m > 32u) {  // 33..256 rows: blocks of 32 rows in grid.y of ONE launch of the 32-row build (contiguous groups, whole K, one weight set)
+    p.row_blocks = (g.m + 31u) / 32u;
+    if (by_id || splits > 1u || sets != nullptr || nl != 16 || UB != 1) return kDynNotEligible;
+  }
+  const int waves = nl == 32 ? kDynWideWaves : kDynWaves;
   const uint32_t st = 64u * (uint32_t)(waves / 2);  // staging threads
   uint32_t rounds = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {

@@ -880,26 +880,12 @@ int act_scored_split(const GemvParams& p, hipStream_t stream, const GemvLaunchOp
   return launch_plan<BITS, UB_>(p, stream, plan, ws);
 }
 
-// Act::DynChunks32: 33..128 rows in launches of up to 64 rows (the 64-row build: four A operands per unpacked B fragment), of 32 where
-// that build does not take the layer (2-bit); each launch streams the weights once more - still ahead of 16-row passes and of dequantise +
-// dense GEMM (profiles/r04/linear_crossover.txt).  Every chunk is checked before the first is launched.
+// Act::DynChunks32: 33..128 rows in ONE launch of the 32-row build, the blocks of 32 rows in grid.y (the row blocks of a column tile run side by side
+// and share its packed rows through L2): ~10 % ahead of one launch per 32 rows, and ahead of 16-row passes and of dequantise + dense GEMM up
+// to 128 rows (profiles/r04/sweep_rows_in_grid_y.txt, linear_crossover.txt).
 template <int BITS>
 int act_dyn_chunks(const GemvParams& p, hipStream_t stream, int cpl) {
-  GemvParams q = p;
-  int st = kGemvDynNotEligible;
-  for (uint32_t chunk = 64u; chunk >= 32u && st == kGemvDynNotEligible; chunk /= 2u) {
-    st = launch_all_or_nothing([&]() -> int {
-      int s = XBIT_OK;
-      for (uint32_t r0 = 0; r0 < p.m && s == XBIT_OK; r0 += chunk) {
-        q.m = p.m - r0 < chunk ? p.m - r0 : chunk;
-        q.a = p.a + (size_t)r0 * p.k;
-        q.out = p.out + (size_t)r0 * p.n;
-        s = launch_gemv_dyn(q, BITS, stream, cpl, 16, true, false, nullptr);
-      }
-      return s;
-    });
-  }
-  return st;
+  return launch_gemv_dyn(p, BITS, stream, cpl, 16, true, false, nullptr);
 }
 
 // Act::MfmaDefault: this file's kernel on tiles of the default width.  Weight loads are plain by default: equal to nontemporal when the

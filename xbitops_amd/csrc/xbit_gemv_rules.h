@@ -48,7 +48,7 @@ enum class Act : uint8_t {
                       // beyond the build's staging rounds: the same plan on the round-2 split kernel
   ScoredSplit,        // plan_split(): tile width and split count by score; one row with 16 or >= 24 units per range: staged-operand split
                       // build, else the round-2 split kernel (up to 4 rows)
-  DynChunks32,        // staged-operand kernel, rows in launches of up to 64 (32 at 2 bits); each streams the weights once more
+  DynChunks32,        // staged-operand kernel, 32-row build, the blocks of 32 rows in grid.y of one launch (not at 2 bits)
   DynWhole,           // staged-operand kernel, whole-K tiles of the default width
   DynNarrow,          // staged-operand kernel, whole-K tiles of 16 columns (8 lanes side by side)
   Mfma16Col,          // round-2 kernel, 16-column tiles
@@ -89,8 +89,8 @@ constexpr Rule kRules[] = {
     {"scored split plan, 1-4 rows (what the fill-once plan does not take)", kAllBits, 1, 4, 256, kAny, 0, kAny, 0, kAny, 0, 176, 0, kGroupC | kNoScored, Act::ScoredSplit,
      "profiles/r02/sweep_split_plans_fine.txt, sweep_split_plans_other_bits.txt; profiles/r03/sweep_split_dyn.txt (which kernel runs the plan)"},
     // ---- more than 32 rows on many tiles: launches of 32 ---------------------------------------------------------------------------
-    {"33-128 rows, >= 192 tiles: launches of up to 64 rows", kAllBits, 33, 128, 0, kAny, 0, kAny, 192, kAny, 0, kAny, kGroupA, 0, Act::DynChunks32,
-     "profiles/r03/sweep_rows_17_32.txt, linear_crossover_after_chunks_of_32.txt (4096x11008 w4 at 64 rows: 22.1 us)"},
+    {"33-128 rows, >= 192 tiles: one launch, blocks of 32 rows in grid.y", kAllBits, 33, 128, 0, kAny, 0, kAny, 192, kAny, 0, kAny, kGroupA, 0, Act::DynChunks32,
+     "profiles/r04/sweep_rows_in_grid_y.txt (4096x11008 w4 at 64 / 128 rows: 21.2 / 40.4 us; launches of 32: 23.4 / 45.7; 16-row passes: 26.9 / 50.2), linear_crossover.txt"},
     // ---- the staged-operand kernel, whole K ----------------------------------------------------------------------------------------
     {"17-32 rows, >= 192 tiles: 32-row build", kAllBits, 17, 32, 0, kAny, 0, kAny, 192, kAny, 0, kAny, kGroupA, 0, Act::DynWhole,
      "profiles/r03/sweep_rows_17_32.txt (4096x11008 w4 15.2 -> 11.5 us; few tiles lose: 4096x4096 7.4 -> 8.6)"},

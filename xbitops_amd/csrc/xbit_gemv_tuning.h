@@ -11,6 +11,7 @@
 //   forced launches of the staged-operand kernel (xbit_gemv_dyn.h):
 //     300  automatic tile   301  16-column tiles   302-304  32 / 48 / 64 columns   310-314  the same with plain loads   320  stamped   321  v_dot2 accumulate
 //     340  128-column tiles   341-343  128- / 64- / 48-column lane maps narrowed to fill the chip   344-347  probes of the 128-column tiles
+//     348  more than 32 rows as blocks of 32 in grid.y of ONE launch   349  ... as launches of 32 rows
 //   forced launches of the round-2 kernel (M = 1 unless noted): 11-25, 28, 39, 51-56, 63, 64, 105-109, 135-140, 164, 170-177, 183, 190-192, 206,
 //     214, 229-243, 272, 274; 16- / 4-row passes: 180, 181, 188, 189, 193, 197-200
 #pragma once
@@ -34,6 +35,18 @@ int forced_dyn(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& op
     const int dcpl = variant == 343 ? 3 : 4, dnl = variant <= 341 ? 32 : 16;
     const uint32_t tcols = variant != 340 ? fill_tcols(p.n, (uint32_t)(dnl * dcpl), (uint32_t)dcpl) : 0u;
     return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, true, false, nullptr, 1, nullptr, nullptr, tcols);
+  }
+  if (variant == 348 && p.m > 32u) return launch_gemv_dyn(p, BITS, stream, c.cpl, 16, true, false, nullptr);  // 33..256 rows: blocks of 32 rows in grid.y of the 32-row build (= production up to 128)
+  if (variant == 349 && p.m > 32u) {  // launches of 32 rows (round 3's chunks)
+    GemvParams q = p;
+    int s_ = XBIT_OK;
+    for (uint32_t r0 = 0; r0 < p.m && s_ == XBIT_OK; r0 += 32u) {
+      q.m = p.m - r0 < 32u ? p.m - r0 : 32u;
+      q.a = p.a + (size_t)r0 * p.k;
+      q.out = p.out + (size_t)r0 * p.n;
+      s_ = launch_gemv_dyn(q, BITS, stream, c.cpl, 16, true, false, nullptr);
+    }
+    return s_;
   }
   if (p.m > 32u && p.m <= 128u) return act_dyn_chunks<BITS>(p, stream, c.cpl);
   if (p.m > 32u) return kGemvDynNotEligible;
@@ -89,7 +102,7 @@ int launch_variant(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts
     return launch_by_rules<BITS>(p, stream, opts, hooks);
   }
   // ---- forced launches of the staged-operand kernel; a shape it does not take falls back to the round-2 kernels, unsplit
-  if (variant >= 300 && variant <= 347) {
+  if (variant >= 300 && variant <= 349) {
     const int st = forced_dyn<BITS>(p, stream, opts, variant);
     if (st != kGemvDynNotEligible) return st;
     hooks.no_dyn = hooks.no_split = true;
