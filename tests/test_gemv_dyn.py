@@ -374,3 +374,64 @@ def test_rows_in_grid_y(bits, cuda_device):
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 31 + k + m)
         y = _run_m(tun if variant > 0 else lib, p, 1, cuda_device, variant)
         _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, k, n, g, m, variant), k=k)
+
+
+# ---- xbit_gemv_rows.h: 33..128 rows, column groups that share one LDS image of the activations ------------------------------------------------
+
+@pytest.mark.parametrize("bits", range(3, 9))
+@pytest.mark.parametrize("variant", [351, 352, 353, 354])
+def test_shared_activation_tile_every_shape(bits, variant, cuda_device):
+    """Every (columns per group, groups per workgroup) build of the shared-activation-tile kernel: a last workgroup with idle column groups, an
+    edge tile, a ragged last block of rows, K that ends inside a unit / inside an octet / on an odd element, group sizes 32..K, more groups in
+    the table than the two k-slices' first units name."""
+    tun = _lib.load_tuning()
+    for k, n, g, m in [(4096, 1030, 128, 64), (2048, 2048, 64, 33), (8192, 344, 128, 100), (4104, 96, 128, 47), (4097, 1024, 128, 57), (1000, 530, 32, 128),
+                       (1027, 200, 1027, 40), (96, 4096, 32, 65)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 37 + variant + k)
+        y = _run_m(tun, p, 1, cuda_device, variant)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, variant, k, n, g, m), k=k)
+        assert np.array_equal(_bits(y), _bits(_run_m(tun, p, 1, cuda_device, variant)))  # fixed summation order: launch to launch identical
+
+
+@pytest.mark.parametrize("bits", range(3, 9))
+def test_shared_activation_tile_is_what_production_launches(bits, cuda_device):
+    """33..128 rows of a layer with many tiles: production and the forced launch of the chosen shape (variant 350) agree bit for bit; the
+    32-row build in grid.y (348) agrees within the contract (another summation order); 256 rows through 350 as well."""
+    lib, tun = _lib.load(), _lib.load_tuning()
+    for k, n, g, m in [(4096, 11008, 128, 128), (4096, 12288, 128, 64), (2048, 9216, 128, 96)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 41 + m)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m), k=k)
+        assert np.array_equal(_bits(y), _bits(_run_m(tun, p, 1, cuda_device, 350)))
+        _close(_run_m(tun, p, 1, cuda_device, 348), y_ref, (bits, k, n, g, m, 348), k=k)
+    p = synth.make_problem(2048, 3000, bits, 128, m=256, seed=bits + 256)
+    _close(_run_m(tun, p, 1, cuda_device, 350), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, 128, bits, 2048, 1, oracle.RNE), (bits, 256), k=2048)
+
+
+@pytest.mark.parametrize("bits", range(3, 9))
+def test_shared_activation_tile_large_scale_takes_the_spliced_form(bits, cuda_device):
+    """A scale too large for the subnormal form (one infinite, one NaN elsewhere) switches ITS workgroups - all column groups of them - to the
+    spliced form: unaffected columns equal the oracle, affected ones as the oracle says."""
+    lib = _lib.load()
+    k, n, g, m = 4096, 9216, 128, 48
+    p = synth.make_problem(k, n, bits, g, m=m, seed=bits + 900)
+    sc = p.scales.copy()
+    sc[3, 5] = np.float16(30.0)
+    sc[7, 700] = np.float16(np.inf)
+    sc[31, 9215] = np.float16(np.nan)
+    p2 = synth.Problem(k, n, bits, g, m, p.qweight, sc, p.qzeros, p.act)
+    y, y_ref = _run_rows(lib, p2, 1, cuda_device), oracle.gemv(p2.act, p2.qweight, p2.scales, p2.qzeros, g, bits, k, 1, oracle.RNE)
+    finite = np.isfinite(y_ref.astype(np.float32))
+    assert np.array_equal(np.isnan(y.astype(np.float32)), np.isnan(y_ref.astype(np.float32)))
+    _close(y[finite], y_ref[finite], bits, k=k)
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_one_twenty_nine_to_two_fifty_six_rows(bits, cuda_device):
+    """129..256 rows through the production entry point: one launch of the shared-activation-tile kernel from 3 bits up (ragged K, few tiles,
+    group sizes 64 / 32 included), 16-row passes at 2 bits."""
+    lib = _lib.load()
+    for k, n, g, m in [(4096, 11008, 128, 256), (2048, 9216, 64, 129), (4097, 1024, 128, 200), (1024, 4096, 32, 192), (8192, 2048, 128, 160)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 43 + k + m)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m), k=k)

@@ -40,6 +40,11 @@ POINTS = [
     # round 4's rule edits: 128-column tiles from 21504 columns (also at several rows), 17..32 rows of a down-projection on the split build
     (4, 4, 8192, 22016, 128), (8, 2, 4096, 22016, 128), (4, 8, 4096, 28672, 128), (4, 1, 8192, 24576, 128), (4, 24, 22016, 4096, 128), (4, 32, 10240, 2560, 128),
     (5, 20, 16384, 3072, 128), (3, 17, 10240, 5120, 128),
+    # 33..128 rows: the shared-activation-tile kernel's shape choice, and the rule that sends a layer to it
+    (4, 128, 3072, 9216, 128), (4, 96, 6144, 16384, 128), (4, 40, 6656, 6656, 128), (8, 64, 6656, 6656, 128), (3, 128, 6144, 4096, 128), (5, 80, 3072, 9216, 64),
+    (4, 128, 4096, 22016, 128), (4, 64, 6144, 2048, 128),
+    # 129..256 rows
+    (4, 256, 6144, 2048, 128), (4, 192, 3072, 9216, 128), (8, 256, 6656, 6656, 128), (3, 160, 4096, 11008, 64), (4, 256, 6144, 16384, 128), (5, 192, 6144, 4096, 128),
 ]
 QUICK = POINTS[::4]
 
@@ -56,6 +61,9 @@ def candidates(bits, m, k, n, g):
         c.append(("staged-operand, 128 columns", 340, 0))
         if m == 1:
             c.append(("round-2 kernel, 128 columns", 107, 0))
+    if m > 32 and bits >= 3:
+        c += [("32-row build, blocks of rows in grid.y", 348, 0), ("shared activation tile, 2 x 48 columns", 351, 0), ("shared activation tile, 4 x 48 columns", 352, 0),
+              ("shared activation tile, 2 x 64 columns", 353, 0), ("shared activation tile, 4 x 64 columns", 354, 0)]
     if m == 1 and kb >= 256 and t32 <= 256 and g % 128 == 0:
         for s in (2, 3, 4, 6, 8, 12):
             c.append(("staged-operand split x%d, 64 columns" % s, 334, s))

@@ -24,6 +24,8 @@ if [[ $PART == *b* ]]; then
   run w4_4096x11008_m8 --shape 4096,11008,4,128,8
   run w4_4096x11008_m16 --shape 4096,11008,4,128,16
   run w4_4096x11008_m32 --shape 4096,11008,4,128,32
+  run w4_4096x11008_m64 --shape 4096,11008,4,128,64
+  run w4_4096x11008_m128 --shape 4096,11008,4,128,128
   run w4_11008x4096_m1_down_proj --shape 11008,4096,4,128,1
   run w5_4096x14336_m1 --shape 4096,14336,5,128,1
   run dequant_w4_4096x11008 --op dequant --shape 4096,11008,4,128,1

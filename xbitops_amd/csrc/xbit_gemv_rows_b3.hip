@@ -1,0 +1,8 @@
+// xbit_gemv_rows_b3.hip — 3-bit instantiation of the shared-activation-tile GEMV for 33..256 rows (see xbit_gemv_rows.h).
+#include "xbit_gemv_rows.h"
+
+namespace xbit {
+
+int launch_gemv_rows_b3(const GemvParams& p, hipStream_t stream, int cpl, int ncg) { return rows::launch_rows_bits<3>(p, stream, cpl, ncg); }
+
+}  // namespace xbit

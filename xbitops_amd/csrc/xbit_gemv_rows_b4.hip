@@ -1,0 +1,8 @@
+// xbit_gemv_rows_b4.hip — 4-bit instantiation of the shared-activation-tile GEMV for 33..256 rows (see xbit_gemv_rows.h).
+#include "xbit_gemv_rows.h"
+
+namespace xbit {
+
+int launch_gemv_rows_b4(const GemvParams& p, hipStream_t stream, int cpl, int ncg) { return rows::launch_rows_bits<4>(p, stream, cpl, ncg); }
+
+}  // namespace xbit

@@ -1,0 +1,8 @@
+// xbit_gemv_rows_b6.hip — 6-bit instantiation of the shared-activation-tile GEMV for 33..256 rows (see xbit_gemv_rows.h).
+#include "xbit_gemv_rows.h"
+
+namespace xbit {
+
+int launch_gemv_rows_b6(const GemvParams& p, hipStream_t stream, int cpl, int ncg) { return rows::launch_rows_bits<6>(p, stream, cpl, ncg); }
+
+}  // namespace xbit

@@ -12,13 +12,14 @@ import torch
 
 from . import ops, packing
 
-# Rows served by the fused kernel.  Up to 32 rows are one launch that unpacks every weight once; beyond that the library
-# launches 32 rows at a time (or 16-row passes on few-column layers), and the weights are streamed once per launch.  Measured
-# against dequantise + torch's dense fp16 GEMM, cold weights (profiles/r03/linear_crossover.txt, us per call): 4096x11008 w4
-# 11.1 against 45.1 at 32 rows, 22.1 / 48.8 at 64, 54.6 / 60.5 at 128; 4096x4096 22.5 / 43.4 at 128; 8192x8192 84 / 107 at
-# 128.  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM), so the fused one keeps
-# the lead up to about 128 rows.
-GEMV_MAX_ROWS = 128
+# Rows served by the fused kernel.  Up to 32 rows are one launch that unpacks every weight once; beyond that ONE launch takes
+# the rows in blocks of 32 (from 3 bits up: column groups that share the activation tile, csrc/xbit_gemv_rows.h, up to 256
+# rows; 2-bit: 16-row passes, up to 128).  Measured against dequantise + torch's dense fp16 GEMM, cold weights
+# (profiles/r04/linear_crossover.txt, sweep_rows_192_256.txt, us per call): 4096x11008 w4 11.9 against 45.2 at 32 rows,
+# 18.7 / 48.3 at 64, 29.8 / 60.4 at 128, 54.7 / 72.9 at 256.  The dense path starts near 40 us whatever the row count (19 us
+# of dequant + a small-M GEMM) and gains 0.1 us per row; the fused one gains 0.2.
+GEMV_MAX_ROWS = 256
+GEMV_MAX_ROWS_2BIT = 128
 # ... for layers the multi-row builds take: a group size that is a power-of-two multiple of 32 (64 at 2 bits), ANY in_features (round 4:
 # a row length that is no multiple of 8 is masked where it is staged; 7166x4096 w4 at 32 rows 17.2 us).  Other group sizes (48, 80, 96 ...)
 # run the by-id builds, 32 rows per launch (4096x4096 w4 at group 48: 16.6 us at 24 rows, 29.6 at 40 - profiles/r04/sweep_ragged_shapes.txt),
@@ -39,7 +40,9 @@ def fused_rows_limit(in_features: int, groupsize: int, bits: int) -> int:
     unit = 64 if bits == 2 else 32
     q = groupsize // unit
     regular = groupsize % unit == 0 and q >= 1 and (q & (q - 1)) == 0
-    return GEMV_MAX_ROWS if regular else GEMV_MAX_ROWS_OTHER
+    if not regular:
+        return GEMV_MAX_ROWS_OTHER
+    return GEMV_MAX_ROWS_2BIT if bits == 2 else GEMV_MAX_ROWS
 
 
 class QuantLinear(torch.nn.Module):
