@@ -68,7 +68,7 @@ static void run_candidate(const char* name, uint32_t k, uint32_t n, uint32_t m, 
   auto kern = xbit::rows::gemv_rows_kernel<BITS, CPL, NCG, NW>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto launch = [&](int c) {
-    hipLaunchKernelGGL(kern, dim3(xtiles, row_blocks), dim3(64 * NW), lds, stream, qw[c], n, xtiles, kw, units, act, sc[c], qz[c], out, k, groups, zw, 1u, m, tab_groups, gshift, red_dwords);
+    hipLaunchKernelGGL(kern, dim3(8u * ((xtiles + 7u) / 8u) * row_blocks), dim3(64 * NW), lds, stream, qw[c], n, xtiles, kw, units, act, sc[c], qz[c], out, k, groups, zw, 1u, m, tab_groups, gshift, red_dwords);
   };
   CK(hipMemsetAsync(out, 0xFF, (size_t)m * n * 2, stream));
   launch(0);

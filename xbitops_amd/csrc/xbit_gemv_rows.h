@@ -4,7 +4,7 @@
 // Why a second kernel shape.  Above 32 rows gemv_dyn_kernel (xbit_gemv_dyn.h) takes 0.31 us per row on 4096x11008 whichever way the rows are cut
 // (blocks of 32 rows in grid.y, a 64-row build: profiles/r04/sweep_rows_in_grid_y.txt): every workgroup owns 48-64 columns and pulls ALL
 // M x K x 2 bytes of activations through its CU's vector-memory path - 1 MB at 128 rows for 98 KB of packed weights.  Here a workgroup of eight
-// waves owns NCG column groups of 16 * CPL columns (NCG = 2 or 4) and one block of 32 rows (grid.y = row blocks).  Its waves are (column group
+// waves owns NCG column groups of 16 * CPL columns (NCG = 2 or 4) and one block of 32 rows.  Its waves are (column group
 // cg, k-slice ks); the NCG waves of one k-slice work on the SAME unit of K at the same time and share ONE LDS image of that unit's activations,
 // which they fetch together - 1 / NCG of it each, one unit ahead, double-buffered - with one workgroup barrier per unit.  Activation bytes per
 // weight byte drop by NCG.  Everything else is gemv_dyn_kernel's: the packed layout and lane map (16 lanes x CPL adjacent columns, 4 k-slots per
@@ -63,7 +63,15 @@ __global__ void __launch_bounds__(64 * NW)
   const int tid = threadIdx.x, lane = tid & 63, kl = lane / NL, nl = lane % NL;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cg = wv % NCG, ks = wv / NCG;  // column group, k-slice: the sibling waves of a k-slice are neighbours
-  const uint32_t xt = xcd_tile(blockIdx.x, xtiles), tile = xt * (uint32_t)NCG + (uint32_t)cg, rb = blockIdx.y;
+  // Workgroup id -> (column tile xt, row block rb).  Ids go round the 8 XCDs; XCD x owns a contiguous run of column tiles (xcd_tile's split) and ALL row
+  // blocks of each, one after the other: the row blocks of a tile then share its packed rows through ONE L2 instead of fetching them once per XCD
+  // (4096x11008 w4 at 128 rows with the row blocks in grid.y: 3.9x the algorithmic bytes over the fabric, profiles/r04/bench_before_xcd_rows/).  The grid
+  // is padded to whole runs; a workgroup whose slot is past its XCD's run leaves at once.
+  const uint32_t row_blocks = (m + (uint32_t)MT - 1u) / (uint32_t)MT;
+  const uint32_t xq = xtiles >> 3, xr = xtiles & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t xl = slot / row_blocks, rb = slot % row_blocks;
+  if (xl >= xq + (xcd < xr ? 1u : 0u)) return;
+  const uint32_t xt = (xcd < xr ? xcd * (xq + 1u) : xr * (xq + 1u) + (xcd - xr) * xq) + xl, tile = xt * (uint32_t)NCG + (uint32_t)cg;
   a += (size_t)rb * MT * k;
   out += (size_t)rb * MT * n;
   const uint32_t rows = m - rb * MT < (uint32_t)MT ? m - rb * MT : (uint32_t)MT;
@@ -304,7 +312,7 @@ int launch_rows_one(const GemvParams& g, hipStream_t stream, uint32_t units, uin
   GemvParams q = g;
   uint32_t xt = xtiles, un = units, tg = tab_groups, gs = gshift;
   void* args[] = {&q.qweight, &q.n, &xt, &q.kw, &un, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias, &q.m, &tg, &gs, &red_dwords};
-  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(xtiles, row_blocks), dim3(64 * NW), lds, stream, args);
+  return launch_raw_dynamic(reinterpret_cast<const void*>(kern), dim3(8u * ((xtiles + 7u) / 8u) * row_blocks), dim3(64 * NW), lds, stream, args);  // whole runs of column tiles per XCD x row blocks
 }
 
 // What a launch costs, in us: rounds of 256 workgroups (one per CU: the LDS of one fills more than half a CU's) x the time of one workgroup.  A workgroup's
