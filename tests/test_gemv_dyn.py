@@ -379,9 +379,9 @@ def test_rows_in_grid_y(bits, cuda_device):
 # ---- xbit_gemv_rows.h: 33..128 rows, column groups that share one LDS image of the activations ------------------------------------------------
 
 @pytest.mark.parametrize("bits", range(3, 9))
-@pytest.mark.parametrize("variant", [351, 352, 353, 354])
+@pytest.mark.parametrize("variant", [351, 352, 353, 354, 355, 356])
 def test_shared_activation_tile_every_shape(bits, variant, cuda_device):
-    """Every (columns per group, groups per workgroup) build of the shared-activation-tile kernel: a last workgroup with idle column groups, an
+    """Every (columns per group, groups per workgroup, rows per workgroup: 351-354 32 rows, 355 / 356 64) build of the shared-activation-tile kernel: a last workgroup with idle column groups, an
     edge tile, a ragged last block of rows, K that ends inside a unit / inside an octet / on an odd element, group sizes 32..K, more groups in
     the table than the two k-slices' first units name."""
     tun = _lib.load_tuning()

@@ -115,15 +115,16 @@ def test_thirty_three_to_two_fifty_six_rows_are_one_launch(native_lib):
     (xbit_gemv_rows.h; columns per group and groups per workgroup by grid fill), or launches of the staged-operand kernel's 32-row build where that one
     does not take the layer (group sizes it cannot index by k-slot)."""
     # grid: whole runs of column tiles per XCD (8 x ceil(tiles of the workgroup's width / 8)) x blocks of 32 rows, mapped to (tile, block) in the kernel
-    for m, shape, grid in ((33, "3, 2", (120 * 2, 1, 1)), (64, "3, 2", (120 * 2, 1, 1)), (65, "3, 4", (64 * 3, 1, 1)), (128, "3, 4", (64 * 4, 1, 1))):
+    # (up to 64 rows: 32 rows per workgroup; beyond: 64 where the model says so - here 2 x 48 columns x 64 rows, 115 column tiles in runs of 15 per XCD)
+    for m, shape, grid in ((33, "3, 2, 8, 32", (120 * 2, 1, 1)), (64, "3, 2, 8, 32", (120 * 2, 1, 1)), (65, "3, 2, 8, 64", (120 * 2, 1, 1)), (128, "3, 2, 8, 64", (120 * 2, 1, 1))):
         (r,) = plan(native_lib, 4, m, 4096, 11008)
-        assert "gemv_rows_kernel<4, %s, 8>" % shape in r["kernel"] and r["grid"] == grid and r["block"] == (512, 1, 1), (m, r)
+        assert "gemv_rows_kernel<4, %s>" % shape in r["kernel"] and r["grid"] == grid and r["block"] == (512, 1, 1), (m, r)
     (r,) = plan(native_lib, 4, 256, 4096, 11008)  # up to 256 rows (dequantise + dense GEMM takes over beyond: xbitops_amd/linear.py)
-    assert "gemv_rows_kernel<4, 3, 4, 8>" in r["kernel"] and r["grid"] == (64 * 8, 1, 1), r
+    assert "gemv_rows_kernel<4, 3, 4, 8, 64>" in r["kernel"] and r["grid"] == (64 * 4, 1, 1), r
     (r,) = plan(native_lib, 4, 64, 4096, 4096)  # few tiles, up to 128 rows: the 32-row build on the layer's default tiles (here 32 columns: 256 workgroups)
     assert "gemv_dyn_kernel<4, 1, 2, 16, 8, true, 2, 4, 4, 0, false, false, 32, false>" in r["kernel"] and r["grid"] == (128, 2, 1), r
     (r,) = plan(native_lib, 4, 192, 4096, 4096)
-    assert "gemv_rows_kernel<4," in r["kernel"] and r["grid"][0] % (8 * 6) == 0 and r["grid"][1] == 1, r
+    assert "gemv_rows_kernel<4," in r["kernel"] and r["grid"][0] % 8 == 0 and r["grid"][1] == 1, r
     recs = plan(native_lib, 4, 64, 4096, 11008, g=48)  # groups that begin inside a k-block: two launches of the 32-row by-id build
     assert len(recs) == 2 and all("gemv_dyn_kernel<4," in r["kernel"] for r in recs), recs
     recs = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit has no 32-row build: 16-row passes of the round-2 kernel

@@ -64,6 +64,8 @@ def candidates(bits, m, k, n, g):
     if m > 32 and bits >= 3:
         c += [("32-row build, blocks of rows in grid.y", 348, 0), ("shared activation tile, 2 x 48 columns", 351, 0), ("shared activation tile, 4 x 48 columns", 352, 0),
               ("shared activation tile, 2 x 64 columns", 353, 0), ("shared activation tile, 4 x 64 columns", 354, 0)]
+        if m > 64:
+            c += [("shared activation tile, 2 x 48 columns x 64 rows", 355, 0), ("shared activation tile, 4 x 48 columns x 64 rows", 356, 0)]
     if m == 1 and kb >= 256 and t32 <= 256 and g % 128 == 0:
         for s in (2, 3, 4, 6, 8, 12):
             c.append(("staged-operand split x%d, 64 columns" % s, 334, s))

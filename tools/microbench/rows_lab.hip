@@ -48,24 +48,24 @@ static _Float16 h_from(uint16_t u) {
 
 typedef int (*gemv_fn)(void*, const void*, const void*, const void*, const void*, int, int, uint32_t, uint32_t, uint32_t, uint8_t, void*);
 
-template <int CPL, int NCG, int NW>
+template <int CPL, int NCG, int NW, int MT>
 static void run_candidate(const char* name, uint32_t k, uint32_t n, uint32_t m, const std::vector<uint32_t*>& qw, const std::vector<uint16_t*>& sc, const std::vector<uint32_t*>& qz,
                           uint16_t* act, uint16_t* out, const std::vector<double>& y_ref, hipStream_t stream) {
   constexpr int BITS = 4, CN = 16 * CPL;
   const uint32_t kw = k / 8, groups = k / 128, zw = (n * 4 + 31) / 32, units = (k / 32 + 3) / 4;
-  const uint32_t tiles = (n + CN - 1) / CN, xtiles = (tiles + NCG - 1) / NCG, row_blocks = (m + 31) / 32;
+  const uint32_t tiles = (n + CN - 1) / CN, xtiles = (tiles + NCG - 1) / NCG, row_blocks = (m + MT - 1) / MT;
   uint32_t gshift = 0;
   while ((32u << gshift) < 128u) ++gshift;
   const uint32_t tab_groups = ((units * 4 - 1u) >> gshift) + 1u;
-  constexpr int NK = NW / NCG, IMG = 4 * 4 * 33 * 4;
-  const uint32_t front = (uint32_t)(NK * 2 * IMG) + (uint32_t)NCG * tab_groups * 64u, red = (uint32_t)NW * 32u * CN;
+  constexpr int NK = NW / NCG, IMG = 4 * 4 * (MT + 1) * 4;
+  const uint32_t front = (uint32_t)(NK * 2 * IMG) + (uint32_t)NCG * tab_groups * 64u, red = (uint32_t)NW * MT * CN;
   const uint32_t red_dwords = front > red ? front : red;
   const size_t lds = (size_t)red_dwords * 4 + NW * 4;
   if (lds > (160u << 10)) {
     printf("%-64s n/a: %zu B of LDS\n", name, lds);
     return;
   }
-  auto kern = xbit::rows::gemv_rows_kernel<BITS, CPL, NCG, NW>;
+  auto kern = xbit::rows::gemv_rows_kernel<BITS, CPL, NCG, NW, MT>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto launch = [&](int c) {
     hipLaunchKernelGGL(kern, dim3(8u * ((xtiles + 7u) / 8u) * row_blocks), dim3(64 * NW), lds, stream, qw[c], n, xtiles, kw, units, act, sc[c], qz[c], out, k, groups, zw, 1u, m, tab_groups, gshift, red_dwords);
@@ -100,7 +100,7 @@ static void run_candidate(const char* name, uint32_t k, uint32_t n, uint32_t m, 
     ch.push_back(ms * 1e3f / 200.f);
   }
   std::sort(ch.begin(), ch.end());
-  printf("%-58s %s bad %zu worst %.2e | grid %u x %u, LDS %zu B | chain med %6.2f min %6.2f us/launch\n", name, bad == 0 ? "ok " : "BAD", bad, worst, xtiles, row_blocks, lds, ch[2], ch[0]);
+  printf("%-58s %s bad %zu worst %.2e | workgroups %u x %u, LDS %zu B | chain med %6.2f min %6.2f us/launch\n", name, bad == 0 ? "ok " : "BAD", bad, worst, xtiles, row_blocks, lds, ch[2], ch[0]);
   fflush(stdout);
 }
 
@@ -179,13 +179,13 @@ int main(int argc, char** argv) {
     std::sort(ch.begin(), ch.end());
     printf("%-64s                                                        chain med %6.2f min %6.2f us/call\n", "production library (xbit_gemv_f16: blocks of 32 rows in grid.y)", ch[2], ch[0]);
   }
-  if (mask & 1u) run_candidate<3, 2, 8>("8 waves: 2 column groups x 4 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 2u) run_candidate<3, 4, 8>("8 waves: 4 column groups x 2 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 4u) run_candidate<4, 2, 8>("8 waves: 2 column groups x 4 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 8u) run_candidate<4, 4, 8>("8 waves: 4 column groups x 2 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 16u) run_candidate<3, 2, 16>("16 waves: 2 column groups x 8 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 32u) run_candidate<3, 4, 16>("16 waves: 4 column groups x 4 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 64u) run_candidate<4, 2, 16>("16 waves: 2 column groups x 8 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
-  if (mask & 128u) run_candidate<4, 4, 16>("16 waves: 4 column groups x 4 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 1u) run_candidate<3, 2, 8, 32>("32 rows: 2 column groups x 4 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 2u) run_candidate<3, 4, 8, 32>("32 rows: 4 column groups x 2 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 4u) run_candidate<4, 2, 8, 32>("32 rows: 2 column groups x 4 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 8u) run_candidate<4, 4, 8, 32>("32 rows: 4 column groups x 2 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 16u) run_candidate<3, 2, 8, 64>("64 rows: 2 column groups x 4 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 32u) run_candidate<3, 4, 8, 64>("64 rows: 4 column groups x 2 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 64u) run_candidate<4, 2, 8, 64>("64 rows: 2 column groups x 4 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 128u) run_candidate<4, 4, 8, 64>("64 rows: 4 column groups x 2 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
   return 0;
 }

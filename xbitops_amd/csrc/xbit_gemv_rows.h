@@ -29,15 +29,15 @@ using dyn::Row;
 using dyn::rsrc_t;
 using dyn::u32x2_t;
 
-constexpr int kRowsWaves = 8, kRowsBlock = 32;  // waves per workgroup, rows per workgroup
+constexpr int kRowsWaves = 8, kRowsBlock = 32;  // waves per workgroup, rows per workgroup (or 64)
 
 // Template parameters: BITS weight width (3..8: one k-block per lane and unit), CPL adjacent columns per lane (3 or 4), NCG column groups per
-// workgroup (2 or 4; 8 / NCG k-slices).
-template <int BITS, int CPL, int NCG, int NW>
+// workgroup (2 or 4; NW / NCG k-slices), NW waves, MT rows per workgroup (32 or 64: MT / 16 A operands per unpacked B fragment).
+template <int BITS, int CPL, int NCG, int NW, int MT>
 __global__ void __launch_bounds__(64 * NW)
     gemv_rows_kernel(const uint32_t* qweight, uint32_t n, uint32_t xtiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales, const uint32_t* qzeros,
                      uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t m, uint32_t tab_groups, uint32_t gshift, uint32_t red_dwords) {
-  constexpr int UB = 1, NL = 16, LK = 4, NK = NW / NCG, MT = kRowsBlock, LA = dyn::kDynLookahead;
+  constexpr int UB = 1, NL = 16, LK = 4, NK = NW / NCG, LA = dyn::kDynLookahead, MG = MT / 16;  // MG: A operands (blocks of 16 rows) per unpacked B fragment
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int CN = NL * CPL;
@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64 * NW)
   constexpr int AR = TASKS / (64 * NCG);     // rounds per wave: the NCG sibling waves fetch a unit together
   static_assert(dyn::dyn_ub<BITS>() == 1, "one k-block per lane and unit");
   static_assert(NCG == 2 || NCG == 4, "column groups per workgroup");
+  static_assert(MT == 32 || MT == 64, "rows per workgroup");
   static_assert(TASKS % (64 * NCG) == 0, "a unit's chunks split evenly over the sibling waves");
   constexpr uint32_t kOob = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];
@@ -190,9 +191,9 @@ __global__ void __launch_bounds__(64 * NW)
   }
   const bool fast = __builtin_amdgcn_readfirstlane((int)any_bad) == 0;
 
-  f4_t acc[2][CPL];
+  f4_t acc[MG][CPL];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < MG; ++g)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) acc[g][c] = f4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(64 * NW)
       }
     });
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {  // rows 0-15, rows 16-31: the same B fragments
+    for (int g = 0; g < MG; ++g) {  // rows 0-15, 16-31, ...: the same B fragments
       const u32x4_t araw = *reinterpret_cast<const u32x4_t*>(a_unit + (j * 4 + oct) * OST + 64 * g);
       const h8_t a_frag = __builtin_bit_cast(h8_t, araw);
 #pragma unroll
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(64 * NW)
   // ---- sum over the k-slices of every column group (the scratch reuses images and tables: every wave is done with them behind this barrier), store
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < MG; ++g)
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
 #pragma unroll
@@ -300,15 +301,15 @@ __global__ void __launch_bounds__(64 * NW)
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------
 
-template <int BITS, int CPL, int NCG, int NW>
+template <int BITS, int CPL, int NCG, int NW, int MT>
 int launch_rows_one(const GemvParams& g, hipStream_t stream, uint32_t units, uint32_t tab_groups, uint32_t gshift) {
-  constexpr int CN = 16 * CPL, NK = NW / NCG, IMG = 4 * 4 * (kRowsBlock + 1) * 4;
-  const uint32_t tiles = (g.n + CN - 1u) / CN, xtiles = (tiles + NCG - 1u) / NCG, row_blocks = (g.m + kRowsBlock - 1u) / kRowsBlock;
-  const uint32_t front = (uint32_t)(NK * 2 * IMG) + (uint32_t)NCG * tab_groups * 64u, red = (uint32_t)(NW * kRowsBlock * CN);  // dwords
+  constexpr int CN = 16 * CPL, NK = NW / NCG, IMG = 4 * 4 * (MT + 1) * 4;
+  const uint32_t tiles = (g.n + CN - 1u) / CN, xtiles = (tiles + NCG - 1u) / NCG, row_blocks = (g.m + MT - 1u) / MT;
+  const uint32_t front = (uint32_t)(NK * 2 * IMG) + (uint32_t)NCG * tab_groups * 64u, red = (uint32_t)(NW * MT * CN);  // dwords
   uint32_t red_dwords = front > red ? front : red;
   const size_t lds = (size_t)red_dwords * 4u + (size_t)NW * 4u;
   if (lds > dyn::kDynMaxLdsById) return kGemvDynNotEligible;
-  auto kern = gemv_rows_kernel<BITS, CPL, NCG, NW>;
+  auto kern = gemv_rows_kernel<BITS, CPL, NCG, NW, MT>;
   GemvParams q = g;
   uint32_t xt = xtiles, un = units, tg = tab_groups, gs = gshift;
   void* args[] = {&q.qweight, &q.n, &xt, &q.kw, &un, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias, &q.m, &tg, &gs, &red_dwords};
@@ -316,25 +317,27 @@ int launch_rows_one(const GemvParams& g, hipStream_t stream, uint32_t units, uin
 }
 
 // What a launch costs, in us: rounds of 256 workgroups (one per CU: the LDS of one fills more than half a CU's) x the time of one workgroup.  A workgroup's
-// time is linear in K, and the slope depends on its shape only (profiles/r04/sweep_rows_shared_tile_v1.txt: 4096 / 8192 / 11008 rows of K on 86..460
-// workgroups; nothing in it - weight stream, activation fetch, barrier, unpack, MFMA - dominates: profiles/r04/rows_lab_ablations.txt, rows_pmc_summary.txt);
-// up to 15 % more when the round is full (shared L2 and fabric); 5..8-bit rows are 12-byte / 16-byte loads of more rows per k-block, the 48-column (12-byte)
-// ones relatively dearer.  The model picks the shape; tools/check_rules.py holds it to 1.08x of the best of the four on held-out layers.
-inline double rows_cost_us(int bits, uint32_t k, uint32_t n, uint32_t m, int cpl, int ncg) {
-  const uint32_t tiles = (n + 16u * (uint32_t)cpl - 1u) / (16u * (uint32_t)cpl), row_blocks = (m + (uint32_t)kRowsBlock - 1u) / (uint32_t)kRowsBlock;
+// time is linear in K, and the slope depends on its shape only (profiles/r04/sweep_rows_shared_tile_v1.txt, rows_lab_64_rows.txt: 4096 / 8192 / 11008 rows of K on
+// 86..460 workgroups; nothing in it - weight stream, activation fetch, barrier, unpack, MFMA - dominates: profiles/r04/rows_lab_ablations.txt,
+// rows_pmc_summary.txt); 7 % more when the round is full (shared L2 and fabric); 5..8-bit rows are 12-byte / 16-byte loads of more rows per k-block, the
+// 48-column (12-byte) ones relatively dearer.  64 rows per workgroup cost 1.3x the time of 32.  The model picks the shape; tools/check_rules.py holds it to
+// 1.08x of the best of the forced ones on held-out layers.
+inline double rows_cost_us(int bits, uint32_t k, uint32_t n, uint32_t m, int cpl, int ncg, int mt) {
+  const uint32_t tiles = (n + 16u * (uint32_t)cpl - 1u) / (16u * (uint32_t)cpl), row_blocks = (m + (uint32_t)mt - 1u) / (uint32_t)mt;
   const uint32_t wgs = ((tiles + (uint32_t)ncg - 1u) / (uint32_t)ncg) * row_blocks, rounds = (wgs + 255u) / 256u;
-  const double c0 = ncg == 2 ? (cpl == 3 ? 3.0 : 4.0) : (cpl == 3 ? 5.8 : 6.2), slope = ncg == 2 ? (cpl == 3 ? 13.7 : 14.0) : (cpl == 3 ? 18.8 : 23.4);
+  double c0 = ncg == 2 ? (cpl == 3 ? 3.0 : 4.0) : (cpl == 3 ? 5.8 : 6.2), slope = ncg == 2 ? (cpl == 3 ? 13.7 : 14.0) : (cpl == 3 ? 18.8 : 23.4);
+  if (mt == 64) c0 = ncg == 2 ? 4.0 : 8.0, slope = ncg == 2 ? 17.4 : 25.4;  // 48-column groups only
   double t = c0 + slope * (double)k / 4096.0;
   if (bits > 4) t *= 1.0 + (double)(bits - 4) / 4.0 * (cpl == 3 ? 0.32 : 0.15);
   const double per_round = (double)wgs / (double)rounds / 256.0;
-  return (double)rounds * t * (1.0 + 0.15 * (per_round < 1.0 ? per_round : 1.0));
+  return (double)rounds * t * (1.0 + 0.07 * (per_round < 1.0 ? per_round : 1.0));
 }
 
 // 33..256 rows of a layer with contiguous groups whose size is a power-of-two multiple of 32, any K, 3..8 bits; kGemvDynNotEligible otherwise.  Columns per
-// group (48 / 64) and groups per workgroup (2 / 4) by rows_cost_us, cheapest first; a shape whose tables do not fit in LDS is passed over.
-// `cpl` / `ncg` other than 0 force the shape (measurement: tools/check_rules.py compares the choice with the other three).
+// group (48 / 64), groups per workgroup (2 / 4) and rows per workgroup (32; 64 with 48-column groups) by rows_cost_us, cheapest first; a shape whose tables do
+// not fit in LDS is passed over.  `cpl` / `ncg` / `mt` other than 0 force the shape (measurement: tools/check_rules.py compares the choice with the others).
 template <int BITS>
-int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0, int force_ncg = 0) {
+int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0, int force_ncg = 0, int force_mt = 0) {
   if constexpr (dyn::dyn_ub<BITS>() != 1) {
     return kGemvDynNotEligible;  // 2-bit: two k-blocks per unit (the 32-row builds do not fit into 256 registers)
   } else {
@@ -351,27 +354,32 @@ int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0,
     if ((uint64_t)units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31) ||
         (uint64_t)g.m * g.k * 2u >= (1ull << 31))
       return kGemvDynNotEligible;
-    auto launch = [&](int cpl, int ncg) -> int {
-      if (cpl == 4) return ncg == 4 ? launch_rows_one<BITS, 4, 4, kRowsWaves>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 4, 2, kRowsWaves>(g, stream, units, tab_groups, gshift);
-      return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves>(g, stream, units, tab_groups, gshift);
+    auto launch = [&](int cpl, int ncg, int mt) -> int {
+      if (mt == 64) {  // four A operands per unpacked B fragment: 48-column groups only (64-column ones never won: profiles/r04/rows_lab_64_rows.txt)
+        if (cpl != 3) return kGemvDynNotEligible;
+        return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 64>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 64>(g, stream, units, tab_groups, gshift);
+      }
+      if (cpl == 4) return ncg == 4 ? launch_rows_one<BITS, 4, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 4, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
+      return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
     };
-    if (force_cpl != 0 || force_ncg != 0) {
-      if ((force_cpl != 3 && force_cpl != 4) || (force_ncg != 2 && force_ncg != 4)) return kGemvDynNotEligible;
-      return launch(force_cpl, force_ncg);
+    if (force_cpl != 0 || force_ncg != 0 || force_mt != 0) {
+      if ((force_cpl != 3 && force_cpl != 4) || (force_ncg != 2 && force_ncg != 4) || (force_mt != 32 && force_mt != 64)) return kGemvDynNotEligible;
+      return launch(force_cpl, force_ncg, force_mt);
     }
     struct Shape {
-      int cpl, ncg;
+      int cpl, ncg, mt;
       double cost;
-    } shapes[4] = {{3, 2, 0.0}, {4, 2, 0.0}, {3, 4, 0.0}, {4, 4, 0.0}};
-    for (Shape& sh : shapes) sh.cost = rows_cost_us(BITS, g.k, g.n, g.m, sh.cpl, sh.ncg);
-    for (int i = 0; i < 4; ++i) {  // cheapest first
+    } shapes[6] = {{3, 2, 32, 0.0}, {4, 2, 32, 0.0}, {3, 4, 32, 0.0}, {4, 4, 32, 0.0}, {3, 2, 64, 0.0}, {3, 4, 64, 0.0}};
+    const int count = g.m > 64u ? 6 : 4;  // up to 64 rows a 64-row workgroup has no second block to amortise over: measured slower
+    for (int i = 0; i < count; ++i) shapes[i].cost = rows_cost_us(BITS, g.k, g.n, g.m, shapes[i].cpl, shapes[i].ncg, shapes[i].mt);
+    for (int i = 0; i < count; ++i) {  // cheapest first
       int best = i;
-      for (int j = i + 1; j < 4; ++j)
+      for (int j = i + 1; j < count; ++j)
         if (shapes[j].cost < shapes[best].cost) best = j;
       const Shape sh = shapes[best];
       shapes[best] = shapes[i];
       shapes[i] = sh;
-      const int st = launch(sh.cpl, sh.ncg);
+      const int st = launch(sh.cpl, sh.ncg, sh.mt);
       if (st != kGemvDynNotEligible) return st;
     }
     return kGemvDynNotEligible;

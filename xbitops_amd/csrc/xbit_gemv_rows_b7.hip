@@ -3,6 +3,6 @@
 
 namespace xbit {
 
-int launch_gemv_rows_b7(const GemvParams& p, hipStream_t stream, int cpl, int ncg) { return rows::launch_rows_bits<7>(p, stream, cpl, ncg); }
+int launch_gemv_rows_b7(const GemvParams& p, hipStream_t stream, int cpl, int ncg, int mt) { return rows::launch_rows_bits<7>(p, stream, cpl, ncg, mt); }
 
 }  // namespace xbit

@@ -12,7 +12,8 @@
 //     300  automatic tile   301  16-column tiles   302-304  32 / 48 / 64 columns   310-314  the same with plain loads   320  stamped   321  v_dot2 accumulate
 //     340  128-column tiles   341-343  128- / 64- / 48-column lane maps narrowed to fill the chip   344-347  probes of the 128-column tiles
 //     348  more than 32 rows as blocks of 32 in grid.y of ONE launch   349  ... as launches of 32 rows
-//     350  more than 32 rows: column groups sharing the activation image (xbit_gemv_rows.h), shape chosen; 351-354 forced: 2 x 48, 4 x 48, 2 x 64, 4 x 64 columns
+//     350  more than 32 rows: column groups sharing the activation image (xbit_gemv_rows.h), shape chosen; 351-354 forced: 2 x 48, 4 x 48, 2 x 64, 4 x 64 columns x 32 rows;
+//          355 / 356: 2 x 48 / 4 x 48 columns x 64 rows
 //   forced launches of the round-2 kernel (M = 1 unless noted): 11-25, 28, 39, 51-56, 63, 64, 105-109, 135-140, 164, 170-177, 183, 190-192, 206,
 //     214, 229-243, 272, 274; 16- / 4-row passes: 180, 181, 188, 189, 193, 197-200
 #pragma once
@@ -37,9 +38,10 @@ int forced_dyn(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& op
     const uint32_t tcols = variant != 340 ? fill_tcols(p.n, (uint32_t)(dnl * dcpl), (uint32_t)dcpl) : 0u;
     return launch_gemv_dyn(p, BITS, stream, dcpl, dnl, true, false, nullptr, 1, nullptr, nullptr, tcols);
   }
-  if (variant >= 350 && variant <= 354) {
+  if (variant >= 350 && variant <= 356) {
     if (p.m <= 32u) return kGemvDynNotEligible;
-    return variant == 350 ? launch_gemv_rows(p, BITS, stream) : launch_gemv_rows(p, BITS, stream, variant >= 353 ? 4 : 3, (variant & 1) ? 2 : 4);
+    if (variant >= 355) return launch_gemv_rows(p, BITS, stream, 3, variant == 355 ? 2 : 4, 64);
+    return variant == 350 ? launch_gemv_rows(p, BITS, stream) : launch_gemv_rows(p, BITS, stream, variant >= 353 ? 4 : 3, (variant & 1) ? 2 : 4, 32);
   }
   if (variant == 348 && p.m > 32u) return launch_gemv_dyn(p, BITS, stream, c.cpl, 16, true, false, nullptr);  // 33..256 rows: blocks of 32 rows in grid.y of the 32-row build (= production up to 128)
   if (variant == 349 && p.m > 32u) {  // launches of 32 rows (round 3's chunks)
@@ -107,7 +109,7 @@ int launch_variant(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts
     return launch_by_rules<BITS>(p, stream, opts, hooks);
   }
   // ---- forced launches of the staged-operand kernel; a shape it does not take falls back to the round-2 kernels, unsplit
-  if (variant >= 300 && variant <= 354) {
+  if (variant >= 300 && variant <= 356) {
     const int st = forced_dyn<BITS>(p, stream, opts, variant);
     if (st != kGemvDynNotEligible) return st;
     hooks.no_dyn = hooks.no_split = true;

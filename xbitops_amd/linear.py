@@ -13,11 +13,11 @@ import torch
 from . import ops, packing
 
 # Rows served by the fused kernel.  Up to 32 rows are one launch that unpacks every weight once; beyond that ONE launch takes
-# the rows in blocks of 32 (from 3 bits up: column groups that share the activation tile, csrc/xbit_gemv_rows.h, up to 256
+# the rows in blocks of 32 or 64 (from 3 bits up: column groups that share the activation tile, csrc/xbit_gemv_rows.h, up to 256
 # rows; 2-bit: 16-row passes, up to 128).  Measured against dequantise + torch's dense fp16 GEMM, cold weights
-# (profiles/r04/linear_crossover.txt, sweep_rows_192_256.txt, us per call): 4096x11008 w4 11.9 against 45.2 at 32 rows,
-# 18.7 / 48.3 at 64, 29.8 / 60.4 at 128, 54.7 / 72.9 at 256.  The dense path starts near 40 us whatever the row count (19 us
-# of dequant + a small-M GEMM) and gains 0.1 us per row; the fused one gains 0.2.
+# (profiles/r04/linear_crossover.txt, us per call): 4096x11008 w4 11.8 against 45.5 at 32 rows, 18.0 / 49.6 at 64,
+# 24.3 / 60.5 at 128, 40.1 / 73.2 at 256.  The dense path starts near 40 us whatever the row count (19 us of dequant + a
+# small-M GEMM) and gains 0.12 us per row; the fused one gains about the same from 64 rows on.
 GEMV_MAX_ROWS = 256
 GEMV_MAX_ROWS_2BIT = 128
 # ... for layers the multi-row builds take: a group size that is a power-of-two multiple of 32 (64 at 2 bits), ANY in_features (round 4:
