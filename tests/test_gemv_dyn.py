@@ -427,11 +427,11 @@ def test_shared_activation_tile_large_scale_takes_the_spliced_form(bits, cuda_de
 
 
 @pytest.mark.parametrize("bits", range(2, 9))
-def test_one_twenty_nine_to_two_fifty_six_rows(bits, cuda_device):
-    """129..256 rows through the production entry point: one launch of the shared-activation-tile kernel from 3 bits up (ragged K, few tiles,
+def test_one_twenty_nine_to_five_twelve_rows(bits, cuda_device):
+    """129..512 rows through the production entry point: one launch of the shared-activation-tile kernel from 3 bits up (ragged K, few tiles,
     group sizes 64 / 32 included), 16-row passes at 2 bits."""
     lib = _lib.load()
-    for k, n, g, m in [(4096, 11008, 128, 256), (2048, 9216, 64, 129), (4097, 1024, 128, 200), (1024, 4096, 32, 192), (8192, 2048, 128, 160)]:
+    for k, n, g, m in [(4096, 11008, 128, 256), (2048, 9216, 64, 129), (4097, 1024, 128, 200), (1024, 4096, 32, 192), (8192, 2048, 128, 160), (1024, 9216, 128, 512), (4097, 1024, 128, 384)]:
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 43 + k + m)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m), k=k)

@@ -110,8 +110,8 @@ def test_launch_rules_grid_is_as_recorded(native_lib):
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
-def test_thirty_three_to_two_fifty_six_rows_are_one_launch(native_lib):
-    """33..256 rows: ONE launch over blocks of 32 rows - of the kernel whose column groups share the activation image
+def test_thirty_three_to_five_twelve_rows_are_one_launch(native_lib):
+    """33..512 rows: ONE launch over blocks of 32 / 64 rows - of the kernel whose column groups share the activation image
     (xbit_gemv_rows.h; columns per group and groups per workgroup by grid fill), or launches of the staged-operand kernel's 32-row build where that one
     does not take the layer (group sizes it cannot index by k-slot)."""
     # grid: whole runs of column tiles per XCD (8 x ceil(tiles of the workgroup's width / 8)) x blocks of 32 rows, mapped to (tile, block) in the kernel
@@ -121,6 +121,9 @@ def test_thirty_three_to_two_fifty_six_rows_are_one_launch(native_lib):
         assert "gemv_rows_kernel<4, %s>" % shape in r["kernel"] and r["grid"] == grid and r["block"] == (512, 1, 1), (m, r)
     (r,) = plan(native_lib, 4, 256, 4096, 11008)  # up to 256 rows (dequantise + dense GEMM takes over beyond: xbitops_amd/linear.py)
     assert "gemv_rows_kernel<4, 3, 4, 8, 64>" in r["kernel"] and r["grid"] == (64 * 4, 1, 1), r
+    (r,) = plan(native_lib, 4, 512, 4096, 11008)  # ... and up to 512 rows (kGemvRowsMax); beyond: 16-row passes of the round-2 kernel
+    assert "gemv_rows_kernel<4, 3, 4, 8, 64>" in r["kernel"] and r["grid"] == (64 * 8, 1, 1), r
+    assert "gemv_mfma_kernel<4," in plan(native_lib, 4, 513, 4096, 11008)[0]["kernel"]
     (r,) = plan(native_lib, 4, 64, 4096, 4096)  # few tiles, up to 128 rows: the 32-row build on the layer's default tiles (here 32 columns: 256 workgroups)
     assert "gemv_dyn_kernel<4, 1, 2, 16, 8, true, 2, 4, 4, 0, false, false, 32, false>" in r["kernel"] and r["grid"] == (128, 2, 1), r
     (r,) = plan(native_lib, 4, 192, 4096, 4096)

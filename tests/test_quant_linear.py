@@ -49,16 +49,16 @@ def test_quant_linear_forward(bits, bias, cuda_device):
     w_deq = layer.dequantize()
     assert np.array_equal(w_deq.cpu().numpy().view(np.uint16), w_ref.view(np.uint16))  # bit-exact vs the oracle
     assert (w_deq.float().cpu() - w).abs().max() < (0.05 if bits >= 4 else 0.12)
-    for rows in (1, 5, 16, 40, 128, 200):  # fused path (up to GEMV_MAX_ROWS rows): the oracle GEMV on the same packed buffers
+    for rows in (1, 5, 16, 40, 128, 200, 400):  # fused path (up to GEMV_MAX_ROWS rows): the oracle GEMV on the same packed buffers
         x = (torch.randn(rows, 512, device=cuda_device) * 0.5).half()
         y = layer(x)
         assert y.shape == (rows, 128)
         _assert_close_to_oracle(y, _oracle_forward(layer, x), "bits=%d rows=%d" % (bits, rows))
     # dequant + dense GEMM path (more rows): fp16 GEMM of the oracle's W, fp32 accumulation order unknown
-    x = (torch.randn(300, 512, device=cuda_device) * 0.5).half()
+    x = (torch.randn(600, 512, device=cuda_device) * 0.5).half()
     y = layer(x)
     y_ref = oracle.matvec_f16(x.cpu().numpy(), w_ref).astype(np.float64)
-    assert y.shape == (300, 128)
+    assert y.shape == (600, 128)
     assert (np.abs(y.float().cpu().numpy() - y_ref) <= 2e-3 * np.abs(y_ref) + 1e-3).all()
     assert layer(torch.zeros(2, 3, 512, device=cuda_device).half()).shape == (2, 3, 128)
 
@@ -163,10 +163,10 @@ def test_fused_rows_limit_is_shape_aware():
     instead of 128; general act-order layers whose group table does not fit the by-id builds leave it at 4."""
     from xbitops_amd import linear
 
-    assert linear.fused_rows_limit(4096, 128, 4) == linear.GEMV_MAX_ROWS == 256
-    assert linear.fused_rows_limit(4096, 32, 4) == 256 and linear.fused_rows_limit(4096, 64, 2) == 128 and linear.fused_rows_limit(11008, 256, 8) == 256
+    assert linear.fused_rows_limit(4096, 128, 4) == linear.GEMV_MAX_ROWS == 512
+    assert linear.fused_rows_limit(4096, 32, 4) == 512 and linear.fused_rows_limit(4096, 64, 2) == 128 and linear.fused_rows_limit(11008, 256, 8) == 512
     assert linear.fused_rows_limit(4096, 48, 4) == 32      # odd group size: by-id builds, 32 rows per launch
-    assert linear.fused_rows_limit(7167, 128, 4) == 256    # ragged K: the same builds, masked tail (round 4)
+    assert linear.fused_rows_limit(7167, 128, 4) == 512    # ragged K: the same builds, masked tail (round 4)
     assert linear.fused_rows_limit(4096, 32, 2) == 32      # 2-bit needs groups of 64 and more
     assert linear.fused_rows_limit(4096, 96, 4) == 32      # 32 x odd
     assert linear.GIDX_GEMV_MAX_ROWS_OTHER < linear.GIDX_GEMV_MAX_ROWS

@@ -23,7 +23,7 @@ SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 14336), (14336, 409
           (8192, 3584), (8192, 28672), (28672, 8192), (4096, 32000), (8192, 22016), (4096, 6144), (12288, 3072), (16384, 6144), (28672, 6144), (12288, 8192),
           (20480, 2560), (32768, 1024), (4096, 512), (2048, 8192), (256, 64), (7168, 4096), (3072, 9216), (6656, 6656)]
 GROUPS = [128, 64, 32, 96]
-ROWS = [1, 2, 4, 5, 8, 9, 16, 17, 32, 33, 128, 129, 256, 257]
+ROWS = [1, 2, 4, 5, 8, 9, 16, 17, 32, 33, 128, 129, 256, 257, 512, 513]
 
 
 def short(kernel: str) -> str:

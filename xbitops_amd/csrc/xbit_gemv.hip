@@ -388,13 +388,13 @@ int launch_gemv(const GemvParams& p, int bits, hipStream_t stream, const GemvLau
   // Whatever the round-2 kernel's alignment rules exclude: any row length k (the reference harness's own K = 7167, main.cc:21;
   // the staged-operand kernel masks the tail where it stages the activations, and reads rows that begin on an odd halfword
   // unaligned), group sizes that are no multiple of 32 (16, 48, 80 ...: the same kernel's by-id builds, ids computed as
-  // k / groupsize), activations and scales on any halfword - up to 128 rows (256 where the one-launch kernels take the layer).  What is left for the column kernel below: more rows
+  // k / groupsize), activations and scales on any halfword - up to 128 rows (512 where the one-launch kernels take the layer).  What is left for the column kernel below: more rows
   // than that, tensors of 2 GiB and more, staged operands beyond LDS (profiles/r04/sweep_ragged_shapes.txt).
-  if (p.m <= 256u && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
+  if (p.m <= kGemvRowsMax && small && !(XBIT_TUNING && (opts.variant == 399 || opts.variant == 398))) {
     // ... by-id layers (act-order-like: odd group sizes) and 2-bit: rows in launches of 32, of 16 where the 32-row build does not take the layer;
     // every chunk is checked before the first goes out
     GemvParams q = p;
-    int st = p.m > 32u ? launch_gemv_rows_or_dyn(p, bits, stream, pick_cpl(p.n)) : kGemvDynNotEligible;  // 33..256 rows: one launch, blocks of 32 rows in grid.y (ragged K: masked where it is staged)
+    int st = p.m > 32u ? launch_gemv_rows_or_dyn(p, bits, stream, pick_cpl(p.n)) : kGemvDynNotEligible;  // 33..512 rows: one launch over blocks of rows (ragged K: masked where it is staged)
     for (uint32_t chunk = 32u; chunk >= 16u && st == kGemvDynNotEligible && p.m <= 128u; chunk /= 2u) {
       st = launch_all_or_nothing([&]() -> int {
         int s = kGemvDynNotEligible;

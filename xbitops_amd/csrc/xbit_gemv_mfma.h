@@ -880,7 +880,7 @@ int act_scored_split(const GemvParams& p, hipStream_t stream, const GemvLaunchOp
   return launch_plan<BITS, UB_>(p, stream, plan, ws);
 }
 
-// Act::DynChunks32: 33..256 rows in ONE launch, blocks of 32 rows in grid.y (xbit_gemv_rows.hip: which kernel).  The kernel whose column groups share one
+// Act::DynChunks32: 33..512 rows in ONE launch over blocks of rows (xbit_gemv_rows.hip: which kernel).  The kernel whose column groups share one
 // LDS image of the activations (xbit_gemv_rows.h: 3..8 bits, groups of a power-of-two multiple of 32): 4096x11008 w4 at 128 rows 40.4 -> 28.6 us, at 64
 // rows 21.7 -> 18.6 (profiles/r04/sweep_rows_shared_tile_v1.txt).  The 32-row build of the staged-operand kernel, whose row blocks of a column tile run side by
 // side and share its packed rows through L2: ~10 % ahead of one launch per 32 rows, and ahead of 16-row passes and of dequantise + dense GEMM up to 128

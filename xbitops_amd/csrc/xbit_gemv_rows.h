@@ -333,7 +333,7 @@ inline double rows_cost_us(int bits, uint32_t k, uint32_t n, uint32_t m, int cpl
   return (double)rounds * t * (1.0 + 0.07 * (per_round < 1.0 ? per_round : 1.0));
 }
 
-// 33..256 rows of a layer with contiguous groups whose size is a power-of-two multiple of 32, any K, 3..8 bits; kGemvDynNotEligible otherwise.  Columns per
+// 33..512 (kGemvRowsMax) rows of a layer with contiguous groups whose size is a power-of-two multiple of 32, any K, 3..8 bits; kGemvDynNotEligible otherwise.  Columns per
 // group (48 / 64), groups per workgroup (2 / 4) and rows per workgroup (32; 64 with 48-column groups) by rows_cost_us, cheapest first; a shape whose tables do
 // not fit in LDS is passed over.  `cpl` / `ncg` / `mt` other than 0 force the shape (measurement: tools/check_rules.py compares the choice with the others).
 template <int BITS>
@@ -341,7 +341,7 @@ int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0,
   if constexpr (dyn::dyn_ub<BITS>() != 1) {
     return kGemvDynNotEligible;  // 2-bit: two k-blocks per unit (the 32-row builds do not fit into 256 registers)
   } else {
-    if (g.m <= (uint32_t)kRowsBlock || g.m > 256u) return kGemvDynNotEligible;
+    if (g.m <= (uint32_t)kRowsBlock || g.m > kGemvRowsMax) return kGemvDynNotEligible;
     const uint32_t dq = g.groupsize / 32u;
     if (g.groupsize % 32u != 0u || (dq & (dq - 1u)) != 0u) return kGemvDynNotEligible;
     if (((uintptr_t)g.qweight | (uintptr_t)g.qzeros) % 4u != 0u || ((uintptr_t)g.a | (uintptr_t)g.scales) % 2u != 0u) return kGemvDynNotEligible;

@@ -89,9 +89,9 @@ constexpr Rule kRules[] = {
     {"scored split plan, 1-4 rows (what the fill-once plan does not take)", kAllBits, 1, 4, 256, kAny, 0, kAny, 0, kAny, 0, 176, 0, kGroupC | kNoScored, Act::ScoredSplit,
      "profiles/r02/sweep_split_plans_fine.txt, sweep_split_plans_other_bits.txt; profiles/r03/sweep_split_dyn.txt (which kernel runs the plan)"},
     // ---- more than 32 rows ---------------------------------------------------------------------------------------------------------
-    {"33-256 rows, >= 192 tiles of 32 columns: one launch, blocks of 32 rows in grid.y", kAllBits, 33, 256, 0, kAny, 0, kAny, 0, kAny, 192, kAny, 0, 0, Act::DynChunks32,
-     "profiles/r04/sweep_rows_shared_tile_v1.txt, sweep_rows_group64_32.txt (group 64 / 32: 4096x11008 w4 at 128 rows 40.0 us against 45.7 in 16-row passes), sweep_rows_192_256.txt (256 rows: 54.7 us against 88.5; dequantise + dense GEMM 72.9: linear_crossover_2.txt), sweep_rows_in_grid_y.txt"},
-    {"129-256 rows, fewer tiles", kAllBits, 129, 256, 0, kAny, 0, kAny, 0, kAny, 0, 191, 0, 0, Act::DynChunks32,
+    {"33-512 rows, >= 192 tiles of 32 columns: one launch over blocks of 32 / 64 rows", kAllBits, 33, 512, 0, kAny, 0, kAny, 0, kAny, 192, kAny, 0, 0, Act::DynChunks32,
+     "profiles/r04/sweep_rows_shared_tile_v1.txt, sweep_rows_group64_32.txt (group 64 / 32: 4096x11008 w4 at 128 rows 40.0 us against 45.7 in 16-row passes), sweep_rows_192_256.txt (256 rows: 54.7 us against 88.5; dequantise + dense GEMM 72.9: linear_crossover_2.txt), sweep_rows_shared_tile_v2.txt (64 rows per workgroup: 38.1), sweep_rows_in_grid_y.txt"},
+    {"129-512 rows, fewer tiles", kAllBits, 129, 512, 0, kAny, 0, kAny, 0, kAny, 0, 191, 0, 0, Act::DynChunks32,
      "profiles/r04/sweep_rows_192_256.txt (4096x4096 w4 at 192 / 256 rows: 17.9 / 18.7 us against 30.0 / 39.8 in 16-row passes)"},
     {"33-128 rows, 96-191 tiles of 32 columns, groups of 128 and more", kAllBits, 33, 128, 0, kAny, 0, kAny, 0, kAny, 96, 191, kGroupA, 0, Act::DynChunks32,
      "profiles/r04/sweep_rows_shared_tile_v1.txt (4096x4096 w4 at 64 / 128 rows: 9.4 / 17.4 us against 12.1 / 21.4; 11008x4096: 21.9 / 40.9 against 27.8 / 51.3), sweep_rows_group64_32.txt (group 32 loses there: 21.6 against 18.4), check_rules_3.txt (6144x2048 at 64 rows loses: 12.2 against 10.9)"},

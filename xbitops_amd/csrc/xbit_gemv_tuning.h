@@ -55,7 +55,7 @@ int forced_dyn(const GemvParams& p, hipStream_t stream, const GemvLaunchOpts& op
     }
     return s_;
   }
-  if (p.m > 32u && p.m <= 256u) return act_dyn_chunks<BITS>(p, stream, c.cpl);
+  if (p.m > 32u && p.m <= kGemvRowsMax) return act_dyn_chunks<BITS>(p, stream, c.cpl);
   if (p.m > 32u) return kGemvDynNotEligible;
   const bool auto_small_n = small_n && p.m <= 8u;
   if (p.m > 4u && auto_small_n && !(variant >= 302 && variant <= 304)) return kGemvDynNotEligible;  // 16-column tiles take one row

@@ -156,10 +156,11 @@ int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, 
 // `sets` the weight sets (count, n, zw, pointers; tile_end is filled in here).  1..16 rows, whole K, tiles of 16 * cpl columns
 // (cpl 3 or 4).  kGemvDynNotEligible when the shape is not for that kernel.
 int launch_gemv_dyn_multi(const GemvParams& p, const GemvSets& sets, int bits, hipStream_t stream, int cpl);  // xbit_gemv_dyn.hip
-// 33..256 rows, 3..8 bits, contiguous groups of a power-of-two multiple of 32: column groups that share one LDS image of the activations
+constexpr uint32_t kGemvRowsMax = 512;  // rows the one-launch kernels for more than 32 rows take (beyond: 16-row passes; QuantLinear goes dense there)
+// 33..kGemvRowsMax rows, 3..8 bits, contiguous groups of a power-of-two multiple of 32: column groups that share one LDS image of the activations
 // (xbit_gemv_rows.h).  cpl / ncg / mt (rows per workgroup) = 0: chosen by a cost model; kGemvDynNotEligible when the shape is not for that kernel.
 int launch_gemv_rows(const GemvParams& p, int bits, hipStream_t stream, int cpl = 0, int ncg = 0, int mt = 0);  // xbit_gemv_rows.hip
-// 33..256 rows in one launch: that kernel or the staged-operand kernel's 32-row build with the blocks of 32 rows in grid.y, by tile and row count
+// 33..kGemvRowsMax rows in one launch: that kernel or the staged-operand kernel's 32-row build with the blocks of 32 rows in grid.y, by tile and row count
 int launch_gemv_rows_or_dyn(const GemvParams& p, int bits, hipStream_t stream, int dyn_cpl);  // xbit_gemv_rows.hip
 int launch_gemv_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);     // xbit_gidx.hip
 int launch_dequant_gidx(const GemvGidxParams& p, int bits, hipStream_t stream);
