@@ -435,3 +435,23 @@ def test_one_twenty_nine_to_five_twelve_rows(bits, cuda_device):
         p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 43 + k + m)
         y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
         _close(y, y_ref, (bits, k, n, g, m), k=k)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 8])
+def test_shared_activation_tile_operands_on_any_halfword(bits, cuda_device):
+    """Activations and scales that begin on an odd halfword (views into larger buffers), 40 and 200 rows: the rows kernel reads them unaligned
+    and gives the result of the aligned call bit for bit."""
+    lib = _lib.load()
+    for k, n, g, m in [(4096, 9216, 128, 40), (2050, 9216, 128, 200)]:
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 47 + m)
+        want = _run_rows(lib, p, 1, cuda_device)
+        a_buf = torch.zeros(p.act.size + 1, dtype=torch.float16, device=cuda_device)
+        s_buf = torch.zeros(p.scales.size + 1, dtype=torch.float16, device=cuda_device)
+        a_buf[1:] = torch.from_numpy(p.act).to(cuda_device).reshape(-1)
+        s_buf[1:] = torch.from_numpy(p.scales).to(cuda_device).reshape(-1)
+        qw, qz = torch.from_numpy(p.qweight).to(cuda_device), torch.from_numpy(p.qzeros).to(cuda_device)
+        out = torch.full((m, n), float("nan"), dtype=torch.float16, device=cuda_device)
+        st = lib.xbit_gemv_f16(out.data_ptr(), a_buf.data_ptr() + 2, qw.data_ptr(), s_buf.data_ptr() + 2, qz.data_ptr(), bits, g, m, k, n, 1, torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "xbit_gemv_f16")
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(want)), (bits, k, n, m)

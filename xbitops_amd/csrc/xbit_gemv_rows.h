@@ -1,22 +1,25 @@
-// xbit_gemv_rows.h — 33..128 activation rows (small-batch prefill, wide speculative decode): the staged-operand GEMV's column groups with the
+// xbit_gemv_rows.h — 33..512 activation rows (small-batch prefill, wide speculative decode): the staged-operand GEMV's column groups with the
 // activation tile SHARED inside a workgroup.  gfx950, bits 3..8, contiguous groups.
 //
 // Why a second kernel shape.  Above 32 rows gemv_dyn_kernel (xbit_gemv_dyn.h) takes 0.31 us per row on 4096x11008 whichever way the rows are cut
 // (blocks of 32 rows in grid.y, a 64-row build: profiles/r04/sweep_rows_in_grid_y.txt): every workgroup owns 48-64 columns and pulls ALL
 // M x K x 2 bytes of activations through its CU's vector-memory path - 1 MB at 128 rows for 98 KB of packed weights.  Here a workgroup of eight
-// waves owns NCG column groups of 16 * CPL columns (NCG = 2 or 4) and one block of 32 rows.  Its waves are (column group
-// cg, k-slice ks); the NCG waves of one k-slice work on the SAME unit of K at the same time and share ONE LDS image of that unit's activations,
-// which they fetch together - 1 / NCG of it each, one unit ahead, double-buffered - with one workgroup barrier per unit.  Activation bytes per
-// weight byte drop by NCG.  Everything else is gemv_dyn_kernel's: the packed layout and lane map (16 lanes x CPL adjacent columns, 4 k-slots per
-// wave, a lane owns whole k-blocks), the row loads a few rows ahead of the MFMA step that needs them (Plan / Row), the bit-exact packed-fp16 W
-// (subnormal form; spliced form for a tile with a scale too large for it), v_mfma_f32_16x16x32_f16 with two A operands (rows 0-15, 16-31) per
-// unpacked B fragment, fp32 sums in a fixed order.
-// Measured (profiles/r04/sweep_rows_shared_tile_v1.txt; tools/microbench/rows_lab.hip is the harness the kernel was developed in), chain period, w4:
-// 4096x11008 at 128 rows 40.4 -> 28.6 us (4 column groups), at 64 rows 21.7 -> 18.6 (2 column groups); 8192x8192 at 128 rows 60.3 -> 34.4.
+// waves owns NCG column groups of 16 * CPL columns (NCG = 2 or 4) and one block of MT = 32 or 64 rows.  Its waves are (column group cg, k-slice ks);
+// the NCG waves of one k-slice work on the SAME unit of K at the same time and share ONE LDS image of that unit's activations, which they fetch
+// together - 1 / NCG of it each, one unit ahead, double-buffered - with one workgroup barrier per unit.  Activation bytes per weight byte drop by
+// NCG, weight bytes and unpack instructions per output by MT / 32.  Everything else is gemv_dyn_kernel's: the packed layout and lane map (16 lanes x
+// CPL adjacent columns, 4 k-slots per wave, a lane owns whole k-blocks), the row loads a few rows ahead of the MFMA step that needs them (Plan /
+// Row), the bit-exact packed-fp16 W (subnormal form; spliced form for a tile with a scale too large for it), v_mfma_f32_16x16x32_f16 with MT / 16 A
+// operands (rows 0-15, 16-31, ...) per unpacked B fragment, fp32 sums in a fixed order.
+// Measured, chain period, w4 (profiles/r04/sweep_rows_shared_tile_v1.txt, _v2.txt, sweep_rows_320_512.txt; tools/microbench/rows_lab.hip is the harness
+// the kernel was developed in): 4096x11008 at 64 / 128 / 256 / 512 rows 21.7 / 40.4 / 75.3 / 172.6 us (grid.y launch; 16-row passes at 512) ->
+// 17.7 / 23.1 / 38.1 / 69.1; 8192x8192 at 128 rows 60.3 -> 34.1.
+// What a workgroup's time follows (profiles/r04/rows_lab_ablations.txt, rows_pmc_summary.txt, rows_lab_64_rows.txt): no single stage - but across the six
+// shapes it is 28-38 ns per wave-level load instruction the workgroup issues (K = 4096: 2 x 48 columns x 32 rows 512 loads, 16.7 us; 4 x 48 x 32: 768,
+// 24.6; 2 x 48 x 64: 768, 21.4; 4 x 48 x 64: 1024, 33.4), whatever else is removed or added: a CU's vector-memory pipeline is the serial resource.
 #pragma once
 
 #include "xbit_gemv_dyn.h"
-
 
 namespace xbit {
 namespace rows {
