@@ -130,5 +130,7 @@ def test_thirty_three_to_five_twelve_rows_are_one_launch(native_lib):
     assert "gemv_rows_kernel<4," in r["kernel"] and r["grid"][0] % 8 == 0 and r["grid"][1] == 1, r
     recs = plan(native_lib, 4, 64, 4096, 11008, g=48)  # groups that begin inside a k-block: two launches of the 32-row by-id build
     assert len(recs) == 2 and all("gemv_dyn_kernel<4," in r["kernel"] for r in recs), recs
-    recs = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit has no 32-row build: 16-row passes of the round-2 kernel
+    (r,) = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit: the same kernel on units of 256 k (32 rows per workgroup only)
+    assert "gemv_rows_kernel<2, " in r["kernel"] and r["kernel"].split(">")[0].endswith(", 8, 32"), r
+    recs = plan(native_lib, 2, 64, 4096, 11008, g=32)  # ... groups of 64 and more; below: 16-row passes of the round-2 kernel
     assert "gemv_mfma_kernel<2," in recs[0]["kernel"], recs

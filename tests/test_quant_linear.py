@@ -164,7 +164,7 @@ def test_fused_rows_limit_is_shape_aware():
     from xbitops_amd import linear
 
     assert linear.fused_rows_limit(4096, 128, 4) == linear.GEMV_MAX_ROWS == 512
-    assert linear.fused_rows_limit(4096, 32, 4) == 512 and linear.fused_rows_limit(4096, 64, 2) == 128 and linear.fused_rows_limit(11008, 256, 8) == 512
+    assert linear.fused_rows_limit(4096, 32, 4) == 512 and linear.fused_rows_limit(4096, 64, 2) == 512 and linear.fused_rows_limit(11008, 256, 8) == 512
     assert linear.fused_rows_limit(4096, 48, 4) == 32      # odd group size: by-id builds, 32 rows per launch
     assert linear.fused_rows_limit(7167, 128, 4) == 512    # ragged K: the same builds, masked tail (round 4)
     assert linear.fused_rows_limit(4096, 32, 2) == 32      # 2-bit needs groups of 64 and more

@@ -45,6 +45,8 @@ POINTS = [
     (4, 128, 4096, 22016, 128), (4, 64, 6144, 2048, 128),
     # 129..256 rows
     (4, 256, 6144, 2048, 128), (4, 192, 3072, 9216, 128), (8, 256, 6656, 6656, 128), (3, 160, 4096, 11008, 64), (4, 256, 6144, 16384, 128), (5, 192, 6144, 4096, 128),
+    # 2-bit beyond 32 rows
+    (2, 64, 4096, 11008, 128), (2, 128, 6656, 6656, 128), (2, 256, 3072, 9216, 64), (2, 96, 6144, 4096, 128),
     # 257..512 rows
     (4, 512, 3072, 9216, 128), (4, 384, 6656, 6656, 128), (8, 512, 4096, 11008, 128), (4, 320, 6144, 2048, 128),
 ]
@@ -63,7 +65,7 @@ def candidates(bits, m, k, n, g):
         c.append(("staged-operand, 128 columns", 340, 0))
         if m == 1:
             c.append(("round-2 kernel, 128 columns", 107, 0))
-    if m > 32 and bits >= 3:
+    if m > 32:
         c += [("32-row build, blocks of rows in grid.y (up to 256 rows)", 348, 0), ("shared activation tile, 2 x 48 columns", 351, 0), ("shared activation tile, 4 x 48 columns", 352, 0),
               ("shared activation tile, 2 x 64 columns", 353, 0), ("shared activation tile, 4 x 64 columns", 354, 0)]
         if m > 64:

@@ -28,7 +28,7 @@ LIB = os.path.join(LIB_DIR, "libxbitops_hip.so")
 TUNING_LIB = os.path.join(LIB_DIR, "libxbitops_hip_tuning.so")
 OBJ_TUNING = os.path.join(CSRC, "_obj_tuning")
 SOURCES = (["xbit_capi.hip", "xbit_dequant.hip", "xbit_gidx.hip", "xbit_gemv.hip", "xbit_gemv_mfma.hip", "xbit_gemv_dyn.hip", "xbit_gemv_rows.hip"] +
-           ["xbit_gemv_mfma_b%d.hip" % b for b in range(2, 9)] + ["xbit_gemv_dyn_b%d.hip" % b for b in range(2, 9)] + ["xbit_gemv_rows_b%d.hip" % b for b in range(3, 9)])
+           ["xbit_gemv_mfma_b%d.hip" % b for b in range(2, 9)] + ["xbit_gemv_dyn_b%d.hip" % b for b in range(2, 9)] + ["xbit_gemv_rows_b%d.hip" % b for b in range(2, 9)])
 TUNING_ONLY_SOURCES = ["xbit_floor.hip"]  # measurement build only: pure-read floors for bench.py (include/xbitops_tuning.h)
 HEADERS = ["xbit_device.h", "xbit_host.h", "xbit_unpack_gen.h", "xbit_gemv_mfma.h", "xbit_gemv_dyn.h", "xbit_gemv_rows.h", "xbit_harness_check.h", "xbit_launch_all.h", "xbit_gemv_rules.h", "xbit_gemv_tuning.h", os.path.join("..", "..", "include", "xbitops_hip.h"),
            os.path.join("..", "..", "include", "xbitops_tuning.h")]

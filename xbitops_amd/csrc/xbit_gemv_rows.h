@@ -1,5 +1,5 @@
 // xbit_gemv_rows.h — 33..512 activation rows (small-batch prefill, wide speculative decode): the staged-operand GEMV's column groups with the
-// activation tile SHARED inside a workgroup.  gfx950, bits 3..8, contiguous groups.
+// activation tile SHARED inside a workgroup.  gfx950, bits 2..8, contiguous groups.
 //
 // Why a second kernel shape.  Above 32 rows gemv_dyn_kernel (xbit_gemv_dyn.h) takes 0.31 us per row on 4096x11008 whichever way the rows are cut
 // (blocks of 32 rows in grid.y, a 64-row build: profiles/r04/sweep_rows_in_grid_y.txt): every workgroup owns 48-64 columns and pulls ALL
@@ -34,13 +34,13 @@ using dyn::u32x2_t;
 
 constexpr int kRowsWaves = 8, kRowsBlock = 32;  // waves per workgroup, rows per workgroup (or 64)
 
-// Template parameters: BITS weight width (3..8: one k-block per lane and unit), CPL adjacent columns per lane (3 or 4), NCG column groups per
+// Template parameters: BITS weight width (2..8; one k-block per lane and unit, two at 2 bits), CPL adjacent columns per lane (3 or 4), NCG column groups per
 // workgroup (2 or 4; NW / NCG k-slices), NW waves, MT rows per workgroup (32 or 64: MT / 16 A operands per unpacked B fragment).
 template <int BITS, int CPL, int NCG, int NW, int MT>
 __global__ void __launch_bounds__(64 * NW)
     gemv_rows_kernel(const uint32_t* qweight, uint32_t n, uint32_t xtiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales, const uint32_t* qzeros,
                      uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t m, uint32_t tab_groups, uint32_t gshift, uint32_t red_dwords) {
-  constexpr int UB = 1, NL = 16, LK = 4, NK = NW / NCG, LA = dyn::kDynLookahead, MG = MT / 16;  // MG: A operands (blocks of 16 rows) per unpacked B fragment
+  constexpr int UB = dyn::dyn_ub<BITS>(), NL = 16, LK = 4, NK = NW / NCG, LA = dyn::kDynLookahead, MG = MT / 16;  // MG: A operands (blocks of 16 rows) per unpacked B fragment
   using P = Plan<BITS, UB, LA>;
   constexpr int R = P::R, S = P::S;
   constexpr int CN = NL * CPL;
@@ -51,7 +51,6 @@ __global__ void __launch_bounds__(64 * NW)
   constexpr int TPR = LK * UB * (32 / CHK);  // chunks (CHK k of one row) per row and unit
   constexpr int TASKS = MT * TPR;            // chunks per unit
   constexpr int AR = TASKS / (64 * NCG);     // rounds per wave: the NCG sibling waves fetch a unit together
-  static_assert(dyn::dyn_ub<BITS>() == 1, "one k-block per lane and unit");
   static_assert(NCG == 2 || NCG == 4, "column groups per workgroup");
   static_assert(MT == 32 || MT == 64, "rows per workgroup");
   static_assert(TASKS % (64 * NCG) == 0, "a unit's chunks split evenly over the sibling waves");
@@ -306,7 +305,7 @@ __global__ void __launch_bounds__(64 * NW)
 
 template <int BITS, int CPL, int NCG, int NW, int MT>
 int launch_rows_one(const GemvParams& g, hipStream_t stream, uint32_t units, uint32_t tab_groups, uint32_t gshift) {
-  constexpr int CN = 16 * CPL, NK = NW / NCG, IMG = 4 * 4 * (MT + 1) * 4;
+  constexpr int CN = 16 * CPL, NK = NW / NCG, IMG = 4 * dyn::dyn_ub<BITS>() * 4 * (MT + 1) * 4;
   const uint32_t tiles = (g.n + CN - 1u) / CN, xtiles = (tiles + NCG - 1u) / NCG, row_blocks = (g.m + MT - 1u) / MT;
   const uint32_t front = (uint32_t)(NK * 2 * IMG) + (uint32_t)NCG * tab_groups * 64u, red = (uint32_t)(NW * MT * CN);  // dwords
   uint32_t red_dwords = front > red ? front : red;
@@ -336,31 +335,34 @@ inline double rows_cost_us(int bits, uint32_t k, uint32_t n, uint32_t m, int cpl
   return (double)rounds * t * (1.0 + 0.07 * (per_round < 1.0 ? per_round : 1.0));
 }
 
-// 33..512 (kGemvRowsMax) rows of a layer with contiguous groups whose size is a power-of-two multiple of 32, any K, 3..8 bits; kGemvDynNotEligible otherwise.  Columns per
+// 33..512 (kGemvRowsMax) rows of a layer with contiguous groups whose size is a power-of-two multiple of 32 (64 at 2 bits), any K; kGemvDynNotEligible otherwise.  Columns per
 // group (48 / 64), groups per workgroup (2 / 4) and rows per workgroup (32; 64 with 48-column groups) by rows_cost_us, cheapest first; a shape whose tables do
 // not fit in LDS is passed over.  `cpl` / `ncg` / `mt` other than 0 force the shape (measurement: tools/check_rules.py compares the choice with the others).
 template <int BITS>
 int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0, int force_ncg = 0, int force_mt = 0) {
-  if constexpr (dyn::dyn_ub<BITS>() != 1) {
-    return kGemvDynNotEligible;  // 2-bit: two k-blocks per unit (the 32-row builds do not fit into 256 registers)
-  } else {
+  {
+    constexpr uint32_t UB = (uint32_t)dyn::dyn_ub<BITS>();  // k-blocks per lane and unit
     if (g.m <= (uint32_t)kRowsBlock || g.m > kGemvRowsMax) return kGemvDynNotEligible;
-    const uint32_t dq = g.groupsize / 32u;
-    if (g.groupsize % 32u != 0u || (dq & (dq - 1u)) != 0u) return kGemvDynNotEligible;
+    const uint32_t dq = g.groupsize / (32u * UB);
+    if (g.groupsize % (32u * UB) != 0u || (dq & (dq - 1u)) != 0u) return kGemvDynNotEligible;
     if (((uintptr_t)g.qweight | (uintptr_t)g.qzeros) % 4u != 0u || ((uintptr_t)g.a | (uintptr_t)g.scales) % 2u != 0u) return kGemvDynNotEligible;
     uint32_t gshift = 0;
     while ((1u << gshift) < dq) ++gshift;
-    const uint32_t kblocks = (g.k + 31u) / 32u, units = (kblocks + 3u) / 4u;
+    const uint32_t kblocks = (g.k + 31u) / 32u, units = (kblocks + 4u * UB - 1u) / (4u * UB);
     uint32_t tab_groups = ((units * 4u - 1u) >> gshift) + 1u;
     if (tab_groups < g.groups) tab_groups = g.groups;
-    const uint64_t unit_bytes = (uint64_t)4 * BITS * g.n * 4u;
+    const uint64_t unit_bytes = (uint64_t)4 * UB * BITS * g.n * 4u;
     if ((uint64_t)units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31) ||
         (uint64_t)g.m * g.k * 2u >= (1ull << 31))
       return kGemvDynNotEligible;
     auto launch = [&](int cpl, int ncg, int mt) -> int {
       if (mt == 64) {  // four A operands per unpacked B fragment: 48-column groups only (64-column ones never won: profiles/r04/rows_lab_64_rows.txt)
-        if (cpl != 3) return kGemvDynNotEligible;
-        return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 64>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 64>(g, stream, units, tab_groups, gshift);
+        if constexpr (UB == 1) {
+          if (cpl != 3) return kGemvDynNotEligible;
+          return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 64>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 64>(g, stream, units, tab_groups, gshift);
+        } else {
+          return kGemvDynNotEligible;  // 2-bit: a unit is 256 k - the images of 64 rows do not fit in LDS
+        }
       }
       if (cpl == 4) return ncg == 4 ? launch_rows_one<BITS, 4, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 4, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
       return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
@@ -373,7 +375,7 @@ int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0,
       int cpl, ncg, mt;
       double cost;
     } shapes[6] = {{3, 2, 32, 0.0}, {4, 2, 32, 0.0}, {3, 4, 32, 0.0}, {4, 4, 32, 0.0}, {3, 2, 64, 0.0}, {3, 4, 64, 0.0}};
-    const int count = g.m > 64u ? 6 : 4;  // up to 64 rows a 64-row workgroup has no second block to amortise over: measured slower
+    const int count = g.m > 64u && UB == 1u ? 6 : 4;  // up to 64 rows a 64-row workgroup has no second block to amortise over: measured slower
     for (int i = 0; i < count; ++i) shapes[i].cost = rows_cost_us(BITS, g.k, g.n, g.m, shapes[i].cpl, shapes[i].ncg, shapes[i].mt);
     for (int i = 0; i < count; ++i) {  // cheapest first
       int best = i;

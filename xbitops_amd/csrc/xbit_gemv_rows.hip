@@ -1,9 +1,10 @@
 // xbit_gemv_rows.hip — bit-width dispatch for the shared-activation-tile GEMV (33..512 rows).  The kernel template lives in xbit_gemv_rows.h and is
-// instantiated once per bit-width in xbit_gemv_rows_b{3..8}.hip so that the widths compile in parallel.
+// instantiated once per bit-width in xbit_gemv_rows_b{2..8}.hip so that the widths compile in parallel.
 #include "xbit_host.h"
 
 namespace xbit {
 
+int launch_gemv_rows_b2(const GemvParams& p, hipStream_t stream, int cpl, int ncg, int mt);
 int launch_gemv_rows_b3(const GemvParams& p, hipStream_t stream, int cpl, int ncg, int mt);
 int launch_gemv_rows_b4(const GemvParams& p, hipStream_t stream, int cpl, int ncg, int mt);
 int launch_gemv_rows_b5(const GemvParams& p, hipStream_t stream, int cpl, int ncg, int mt);
@@ -13,7 +14,7 @@ int launch_gemv_rows_b8(const GemvParams& p, hipStream_t stream, int cpl, int nc
 
 int launch_gemv_rows(const GemvParams& p, int bits, hipStream_t stream, int cpl, int ncg, int mt) {
   switch (bits) {
-    case 2: return kGemvDynNotEligible;  // two k-blocks per lane and unit: no 32-row build fits into 256 registers
+    case 2: return launch_gemv_rows_b2(p, stream, cpl, ncg, mt);
     case 3: return launch_gemv_rows_b3(p, stream, cpl, ncg, mt);
     case 4: return launch_gemv_rows_b4(p, stream, cpl, ncg, mt);
     case 5: return launch_gemv_rows_b5(p, stream, cpl, ncg, mt);

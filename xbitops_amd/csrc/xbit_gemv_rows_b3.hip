@@ -1,4 +1,4 @@
-// xbit_gemv_rows_b3.hip — 3-bit instantiation of the shared-activation-tile GEMV for 33..256 rows (see xbit_gemv_rows.h).
+// xbit_gemv_rows_b3.hip — 3-bit instantiation of the shared-activation-tile GEMV for 33..512 rows (see xbit_gemv_rows.h).
 #include "xbit_gemv_rows.h"
 
 namespace xbit {

@@ -48,7 +48,7 @@ enum class Act : uint8_t {
                       // beyond the build's staging rounds: the same plan on the round-2 split kernel
   ScoredSplit,        // plan_split(): tile width and split count by score; one row with 16 or >= 24 units per range: staged-operand split
                       // build, else the round-2 split kernel (up to 4 rows)
-  DynChunks32,        // 33..128 rows: the shared-activation-tile kernel or the staged-operand kernel's 32-row build, blocks of 32 rows in grid.y of one launch (not at 2 bits)
+  DynChunks32,        // 33..512 rows: the shared-activation-tile kernel or the staged-operand kernel's 32-row build (3 bits and more), one launch over blocks of rows
   DynWhole,           // staged-operand kernel, whole-K tiles of the default width
   DynNarrow,          // staged-operand kernel, whole-K tiles of 16 columns (8 lanes side by side)
   Mfma16Col,          // round-2 kernel, 16-column tiles
@@ -89,6 +89,10 @@ constexpr Rule kRules[] = {
     {"scored split plan, 1-4 rows (what the fill-once plan does not take)", kAllBits, 1, 4, 256, kAny, 0, kAny, 0, kAny, 0, 176, 0, kGroupC | kNoScored, Act::ScoredSplit,
      "profiles/r02/sweep_split_plans_fine.txt, sweep_split_plans_other_bits.txt; profiles/r03/sweep_split_dyn.txt (which kernel runs the plan)"},
     // ---- more than 32 rows ---------------------------------------------------------------------------------------------------------
+    {"2-bit, 33-64 rows, < 320 tiles of 32 columns: 16-row passes", bit_set(2, 2), 33, 64, 0, kAny, 0, kAny, 0, kAny, 0, 319, 0, 0, Act::MfmaDefault,
+     "profiles/r04/sweep_rows_w2.txt (2-bit units are 256 k: two row blocks of a narrow layer do not fill the chip - 4096x4096 at 64 rows 11.0 us against 15.0, 8192x8192 35.2 / 42.4; 4096x11008 wins: 16.4 against 25.6)"},
+    {"2-bit, 65-128 rows, < 192 tiles of 32 columns, K > 4096: 16-row passes", bit_set(2, 2), 65, 128, 129, kAny, 0, kAny, 0, kAny, 0, 191, 0, 0, Act::MfmaDefault,
+     "profiles/r04/check_rules_9.txt (6144x4096 w2 at 96 rows: 25.5 us against 32.9 - the images of two column groups and the table of a K beyond 4096 do not fit in LDS, four groups are too wide for 128 tiles; 4096x4096 at 128 rows stays: 15.2 against 20.1)"},
     {"33-512 rows, >= 192 tiles of 32 columns: one launch over blocks of 32 / 64 rows", kAllBits, 33, 512, 0, kAny, 0, kAny, 0, kAny, 192, kAny, 0, 0, Act::DynChunks32,
      "profiles/r04/sweep_rows_shared_tile_v1.txt, sweep_rows_group64_32.txt (group 64 / 32: 4096x11008 w4 at 128 rows 40.0 us against 45.7 in 16-row passes), sweep_rows_192_256.txt (256 rows: 54.7 us against 88.5; dequantise + dense GEMM 72.9: linear_crossover_2.txt), sweep_rows_shared_tile_v2.txt (64 rows per workgroup: 38.1), sweep_rows_in_grid_y.txt"},
     {"129-512 rows, fewer tiles", kAllBits, 129, 512, 0, kAny, 0, kAny, 0, kAny, 0, 191, 0, 0, Act::DynChunks32,

@@ -157,7 +157,7 @@ int launch_gemv_dyn(const GemvParams& p, int bits, hipStream_t stream, int cpl, 
 // (cpl 3 or 4).  kGemvDynNotEligible when the shape is not for that kernel.
 int launch_gemv_dyn_multi(const GemvParams& p, const GemvSets& sets, int bits, hipStream_t stream, int cpl);  // xbit_gemv_dyn.hip
 constexpr uint32_t kGemvRowsMax = 512;  // rows the one-launch kernels for more than 32 rows take (beyond: 16-row passes; QuantLinear goes dense there)
-// 33..kGemvRowsMax rows, 3..8 bits, contiguous groups of a power-of-two multiple of 32: column groups that share one LDS image of the activations
+// 33..kGemvRowsMax rows, contiguous groups of a power-of-two multiple of 32 (64 at 2 bits): column groups that share one LDS image of the activations
 // (xbit_gemv_rows.h).  cpl / ncg / mt (rows per workgroup) = 0: chosen by a cost model; kGemvDynNotEligible when the shape is not for that kernel.
 int launch_gemv_rows(const GemvParams& p, int bits, hipStream_t stream, int cpl = 0, int ncg = 0, int mt = 0);  // xbit_gemv_rows.hip
 // 33..kGemvRowsMax rows in one launch: that kernel or the staged-operand kernel's 32-row build with the blocks of 32 rows in grid.y, by tile and row count

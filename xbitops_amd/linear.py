@@ -13,14 +13,13 @@ import torch
 from . import ops, packing
 
 # Rows served by the fused kernel.  Up to 32 rows are one launch that unpacks every weight once; beyond that ONE launch takes
-# the rows in blocks of 32 or 64 (from 3 bits up: column groups that share the activation tile, csrc/xbit_gemv_rows.h, up to 512
-# rows; 2-bit: 16-row passes, up to 128).  Measured against dequantise + torch's dense fp16 GEMM, cold weights
+# the rows in blocks of 32 or 64 (column groups that share the activation tile, csrc/xbit_gemv_rows.h, up to 512 rows).  Measured against dequantise + torch's dense fp16 GEMM, cold weights
 # (profiles/r04/linear_crossover.txt, us per call): 4096x11008 w4 11.8 against 45.5 at 32 rows, 18.0 / 49.6 at 64,
 # 24.3 / 60.5 at 128, 40.1 / 75.7 at 256, 69.3 / 89.8 at 384, 79.1 / 94.2 at 512 (8192x8192: 36.8 / 107.5 at 128, 129.9 / 131.9 at
 # 512: level).  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM) and gains 0.1 us per
 # row; the fused one gains 0.15 from 64 rows on - they meet near 512.
 GEMV_MAX_ROWS = 512
-GEMV_MAX_ROWS_2BIT = 128
+GEMV_MAX_ROWS_2BIT = 512  # (profiles/r04/linear_crossover_w2.txt: 4096x11008 w2 at 256 rows 54.7 against 70.8, at 512 rows 92.0 / 94.7)
 # ... for layers the multi-row builds take: a group size that is a power-of-two multiple of 32 (64 at 2 bits), ANY in_features (round 4:
 # a row length that is no multiple of 8 is masked where it is staged; 7166x4096 w4 at 32 rows 17.2 us).  Other group sizes (48, 80, 96 ...)
 # run the by-id builds, 32 rows per launch (4096x4096 w4 at group 48: 16.6 us at 24 rows, 29.6 at 40 - profiles/r04/sweep_ragged_shapes.txt),
