@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
   hipStream_t stream;
   CK(hipStreamCreate(&stream));
   printf("# %ux%u w4 g128, %u rows, %d weight copies\n", k, n, m, copies);
-  const unsigned mask = argc > 4 ? (unsigned)strtoul(argv[4], nullptr, 0) : 0xFFu;
+  const unsigned mask = argc > 4 ? (unsigned)strtoul(argv[4], nullptr, 0) : 0xFFu;  // (the 4-wave builds - bits 8..10 - only on request)
   void* lib = argc > 4 ? nullptr : dlopen("xbitops_amd/lib/libxbitops_hip.so", RTLD_NOW);
   if (lib != nullptr) {
     gemv_fn gemv = (gemv_fn)dlsym(lib, "xbit_gemv_f16");
@@ -186,6 +186,9 @@ int main(int argc, char** argv) {
   if (mask & 16u) run_candidate<3, 2, 8, 64>("64 rows: 2 column groups x 4 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
   if (mask & 32u) run_candidate<3, 4, 8, 64>("64 rows: 4 column groups x 2 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
   if (mask & 64u) run_candidate<4, 2, 8, 64>("64 rows: 2 column groups x 4 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 256u) run_candidate<3, 2, 4, 32>("4 waves, 32 rows: 2 column groups x 2 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 512u) run_candidate<4, 2, 4, 32>("4 waves, 32 rows: 2 column groups x 2 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
+  if (mask & 1024u) run_candidate<3, 2, 4, 64>("4 waves, 64 rows: 2 column groups x 2 k-slices, 48 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
   if (mask & 128u) run_candidate<4, 4, 8, 64>("64 rows: 4 column groups x 2 k-slices, 64 columns each", k, n, m, dqw, dsc, dqz, dact, dout, y_ref, stream);
   return 0;
 }
