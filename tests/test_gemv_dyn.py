@@ -438,6 +438,49 @@ def test_one_twenty_nine_to_five_twelve_rows(bits, cuda_device):
         _close(y, y_ref, (bits, k, n, g, m), k=k)
 
 
+@pytest.mark.parametrize("bits", range(2, 9))
+@pytest.mark.parametrize("variant", [351, 353, 355])
+def test_shared_activation_tile_tables_as_a_window(bits, variant, cuda_device):
+    """The windowed-table builds (xbit_gemv_rows.h, WIN): layers whose tables of all groups do not fit in LDS beside the activation images - a long K at every
+    group size the kernel indexes (a window is 1, 2, 4 ... steps), K that ends inside a window / a unit / on an odd element, a ragged last block of rows, an edge
+    tile, more windows than two (the ring wraps), 64 rows per workgroup at a K that the full tables no longer allow.  Forced shapes: 2 column groups of 48 / 64
+    columns x 32 rows, 2 x 48 x 64 rows; the dry run says the windowed build is what ran."""
+    tun = _lib.load_tuning()
+    shapes = [(28672, 520, 128, 40), (16384, 200, 32, 70), (20481, 96, 64, 70), (65536, 130, 256, 65)]  # (a ragged K goes by the production rule whatever the variant: beyond 64 rows this kernel)
+    if variant == 355:
+        shapes.append((8192, 344, 128, 100))  # 64 groups: too many beside the images of 64 rows only
+    for k, n, g, m in shapes:
+        if bits == 2 and g == 32:
+            g = 64  # 2-bit units are 256 k: groups start at 64
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 53 + variant + k)
+        if not (bits == 2 and variant == 355):  # 2-bit has no 64-row build (round-2 kernel instead, checked all the same)
+            (r,) = _lib.dry_run(tun, lambda: _run_m(tun, p, 1, cuda_device, variant))
+            assert "gemv_rows_kernel<%d," % bits in r["kernel"] and ", true>" in r["kernel"], (bits, variant, k, n, g, m, r)
+        y = _run_m(tun, p, 1, cuda_device, variant)
+        _close(y, oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE), (bits, variant, k, n, g, m), k=k)
+        assert np.array_equal(_bits(y), _bits(_run_m(tun, p, 1, cuda_device, variant)))
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_long_k_rows_production_and_spliced_form(bits, cuda_device):
+    """Production entry point on a long-K layer at 48 and 130 rows (windowed tables), and the same layer with a scale too large for the subnormal form in a LATE
+    group (found by the opening's pass over the tile's scales, not by the first window): affected columns as the oracle says, the others equal to it."""
+    lib = _lib.load()
+    k, n, g = 28672, 1030, 128
+    for m in (48, 130):
+        p = synth.make_problem(k, n, bits, g, m=m, seed=bits * 59 + m)
+        y, y_ref = _run_rows(lib, p, 1, cuda_device), oracle.gemv(p.act, p.qweight, p.scales, p.qzeros, g, bits, k, 1, oracle.RNE)
+        _close(y, y_ref, (bits, k, n, g, m), k=k)
+    sc = p.scales.copy()
+    sc[200, 7] = np.float16(30.0)
+    sc[223, 1029] = np.float16(np.inf)
+    p2 = synth.Problem(k, n, bits, g, p.m, p.qweight, sc, p.qzeros, p.act)
+    y, y_ref = _run_rows(lib, p2, 1, cuda_device), oracle.gemv(p2.act, p2.qweight, p2.scales, p2.qzeros, g, bits, k, 1, oracle.RNE)
+    finite = np.isfinite(y_ref.astype(np.float32))
+    assert np.array_equal(np.isnan(y.astype(np.float32)), np.isnan(y_ref.astype(np.float32)))
+    _close(y[finite], y_ref[finite], bits, k=k)
+
+
 @pytest.mark.parametrize("bits", [3, 4, 8])
 def test_shared_activation_tile_operands_on_any_halfword(bits, cuda_device):
     """Activations and scales that begin on an odd halfword (views into larger buffers), 40 and 200 rows: the rows kernel reads them unaligned

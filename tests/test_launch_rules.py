@@ -118,11 +118,11 @@ def test_thirty_three_to_five_twelve_rows_are_one_launch(native_lib):
     # (up to 64 rows: 32 rows per workgroup; beyond: 64 where the model says so - here 2 x 48 columns x 64 rows, 115 column tiles in runs of 15 per XCD)
     for m, shape, grid in ((33, "3, 2, 8, 32", (120 * 2, 1, 1)), (64, "3, 2, 8, 32", (120 * 2, 1, 1)), (65, "3, 2, 8, 64", (120 * 2, 1, 1)), (128, "3, 2, 8, 64", (120 * 2, 1, 1))):
         (r,) = plan(native_lib, 4, m, 4096, 11008)
-        assert "gemv_rows_kernel<4, %s>" % shape in r["kernel"] and r["grid"] == grid and r["block"] == (512, 1, 1), (m, r)
+        assert "gemv_rows_kernel<4, %s, false>" % shape in r["kernel"] and r["grid"] == grid and r["block"] == (512, 1, 1), (m, r)
     (r,) = plan(native_lib, 4, 256, 4096, 11008)  # up to 256 rows (dequantise + dense GEMM takes over beyond: xbitops_amd/linear.py)
-    assert "gemv_rows_kernel<4, 3, 4, 8, 64>" in r["kernel"] and r["grid"] == (64 * 4, 1, 1), r
+    assert "gemv_rows_kernel<4, 3, 4, 8, 64, false>" in r["kernel"] and r["grid"] == (64 * 4, 1, 1), r
     (r,) = plan(native_lib, 4, 512, 4096, 11008)  # ... and up to 512 rows (kGemvRowsMax); beyond: 16-row passes of the round-2 kernel
-    assert "gemv_rows_kernel<4, 3, 4, 8, 64>" in r["kernel"] and r["grid"] == (64 * 8, 1, 1), r
+    assert "gemv_rows_kernel<4, 3, 4, 8, 64, false>" in r["kernel"] and r["grid"] == (64 * 8, 1, 1), r
     assert "gemv_mfma_kernel<4," in plan(native_lib, 4, 513, 4096, 11008)[0]["kernel"]
     (r,) = plan(native_lib, 4, 64, 4096, 4096)  # few tiles, up to 128 rows: the 32-row build on the layer's default tiles (here 32 columns: 256 workgroups)
     assert "gemv_dyn_kernel<4, 1, 2, 16, 8, true, 2, 4, 4, 0, false, false, 32, false>" in r["kernel"] and r["grid"] == (128, 2, 1), r
@@ -131,6 +131,20 @@ def test_thirty_three_to_five_twelve_rows_are_one_launch(native_lib):
     recs = plan(native_lib, 4, 64, 4096, 11008, g=48)  # groups that begin inside a k-block: two launches of the 32-row by-id build
     assert len(recs) == 2 and all("gemv_dyn_kernel<4," in r["kernel"] for r in recs), recs
     (r,) = plan(native_lib, 2, 64, 4096, 11008)  # 2-bit: the same kernel on units of 256 k (32 rows per workgroup only)
-    assert "gemv_rows_kernel<2, " in r["kernel"] and r["kernel"].split(">")[0].endswith(", 8, 32"), r
+    assert "gemv_rows_kernel<2, " in r["kernel"] and r["kernel"].split(">")[0].endswith(", 8, 32, false"), r
     recs = plan(native_lib, 2, 64, 4096, 11008, g=32)  # ... groups of 64 and more; below: 16-row passes of the round-2 kernel
     assert "gemv_mfma_kernel<2," in recs[0]["kernel"], recs
+
+
+def test_long_k_layers_take_the_windowed_table_build(native_lib):
+    """The tables of ALL groups of a long K do not fit in LDS beside the activation images (K beyond about 14 K at group 128 with 32 rows per workgroup,
+    about 4.6 K with 64): such layers used to fall to the 32-row build in grid.y, which re-reads the activations per 48-64 columns.  They now run the builds of
+    the shared-activation-tile kernel that keep the tables as a ring of two windows (last template argument true; 16 KB of tables whatever K)."""
+    for m in (40, 64, 128, 256, 512):
+        (r,) = plan(native_lib, 4, m, 28672, 8192)  # the 70B down-projection
+        assert "gemv_rows_kernel<4," in r["kernel"] and r["kernel"].split("gemv_rows_kernel<")[1].split(">")[0].endswith(", true"), (m, r)
+        assert r["lds"] <= 156 * 1024, r
+    (r,) = plan(native_lib, 4, 128, 16384, 6144, g=64)  # 256 groups
+    assert "gemv_rows_kernel<4," in r["kernel"] and ", true>" in r["kernel"], r
+    (r,) = plan(native_lib, 4, 128, 4096, 11008)  # short K: the tables of all groups, as before
+    assert ", false>" in r["kernel"], r

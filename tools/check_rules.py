@@ -50,6 +50,10 @@ POINTS = [
     # 257..512 rows
     (4, 512, 3072, 9216, 128), (4, 384, 6656, 6656, 128), (8, 512, 4096, 11008, 128), (4, 320, 6144, 2048, 128),
 ]
+# beyond 32 rows on layers whose tables of all groups do not fit in LDS beside the activation images: the windowed-table builds of the shared-activation-tile kernel
+LONG_K = [(4, 96, 24576, 5120, 128), (4, 256, 28672, 6144, 128), (8, 64, 16384, 7168, 64), (3, 160, 20480, 5120, 128), (2, 128, 6656, 6656, 64), (4, 384, 24576, 1536, 128),
+          (5, 128, 16384, 3072, 32)]
+POINTS += LONG_K
 QUICK = POINTS[::4]
 
 
@@ -81,11 +85,11 @@ def candidates(bits, m, k, n, g):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--slack", type=float, default=1.08)
-    ap.add_argument("--points", default="all", choices=("all", "quick"))
+    ap.add_argument("--points", default="all", choices=("all", "quick", "long_k"))
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     prod, tun = _lib.load(), _lib.load_tuning()
-    points = POINTS if args.points == "all" else QUICK
+    points = POINTS if args.points == "all" else LONG_K if args.points == "long_k" else QUICK
     print("# device %s; period of a dependent chain of launches, cold, us; the automatic launch (production library) against every forced launch; slack %.2f" % (
         torch.cuda.get_device_name(0), args.slack), flush=True)
     failed = 0

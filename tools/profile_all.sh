@@ -1,6 +1,7 @@
 #!/bin/bash
 # Every BASELINE.json config (and the dequant op) through tools/profile_bench.sh, on the GPU box:
-#   bash tools/profile_all.sh gpurun_out/prof_r03 [a|b]      (a / b: half of the list each, to stay inside one gpurun call)
+#   bash tools/profile_all.sh gpurun_out/prof_r03 [a|b|c]    (a / b: half of the list each, to stay inside one gpurun call; c: the metric config, cfg4 and the
+#                                                             launches of the shared-activation-tile kernel only - what a change to xbit_gemv_rows.h touches)
 # Leaves one directory per workload with bench.json.log, bench_kernel_stats.csv, bench_kernel_trace.txt, pmc_traffic.json.
 set -o pipefail
 OUT=${1:-gpurun_out/prof_all}
@@ -31,4 +32,11 @@ if [[ $PART == *b* ]]; then
   run dequant_w4_4096x11008 --op dequant --shape 4096,11008,4,128,1
   run dequant_w4_4096x4096 --op dequant --shape 4096,4096,4,128,1
   run dequant_w3_4096x4096 --op dequant --shape 4096,4096,3,128,1
+fi
+if [[ $PART == *c* ]]; then
+  run cfg2_w4_4096x11008_m1
+  run cfg4_w4_8192x28672_m1_one_gpu --config cfg4
+  run w4_4096x11008_m64 --shape 4096,11008,4,128,64
+  run w4_4096x11008_m128 --shape 4096,11008,4,128,128
+  run w4_28672x8192_m128_down_proj_70b --shape 28672,8192,4,128,128
 fi

@@ -13,7 +13,8 @@
 // operands (rows 0-15, 16-31, ...) per unpacked B fragment, fp32 sums in a fixed order.
 // Measured, chain period, w4 (profiles/r04/sweep_rows_shared_tile_v1.txt, _v2.txt, sweep_rows_320_512.txt; tools/microbench/rows_lab.hip is the harness
 // the kernel was developed in): 4096x11008 at 64 / 128 / 256 / 512 rows 21.7 / 40.4 / 75.3 / 172.6 us (grid.y launch; 16-row passes at 512) ->
-// 17.7 / 23.1 / 38.1 / 69.1; 8192x8192 at 128 rows 60.3 -> 34.1.
+// 17.7 / 23.1 / 38.1 / 69.1; 8192x8192 at 128 rows 60.3 -> 34.1.  Long K (tables as a window, WIN below; profiles/r04/sweep_rows_long_k.txt, sweep_rows_long_k_w2.txt): 28672x8192 at 64 / 128 /
+// 256 / 512 rows 101 / 192 / 380 / 826 us (32-row build in grid.y; 16-row passes at 512) -> 84 / 105 / 203 / 361; 14336x4096 at 256 / 512 rows 96 / 244 -> 55 / 95.
 // What a workgroup's time follows (profiles/r04/rows_lab_ablations.txt, rows_pmc_summary.txt, rows_lab_64_rows.txt): no single stage - but across the six
 // shapes it is 28-38 ns per wave-level load instruction the workgroup issues (K = 4096: 2 x 48 columns x 32 rows 512 loads, 16.7 us; 4 x 48 x 32: 768,
 // 24.6; 2 x 48 x 64: 768, 21.4; 4 x 48 x 64: 1024, 33.4), whatever else is removed or added: a CU's vector-memory pipeline is the serial resource.
@@ -35,8 +36,16 @@ using dyn::u32x2_t;
 constexpr int kRowsWaves = 8, kRowsBlock = 32;  // waves per workgroup, rows per workgroup (or 64)
 
 // Template parameters: BITS weight width (2..8; one k-block per lane and unit, two at 2 bits), CPL adjacent columns per lane (3 or 4), NCG column groups per
-// workgroup (2 or 4; NW / NCG k-slices), NW waves, MT rows per workgroup (32 or 64: MT / 16 A operands per unpacked B fragment).
-template <int BITS, int CPL, int NCG, int NW, int MT>
+// workgroup (2 or 4; NW / NCG k-slices), NW waves, MT rows per workgroup (32 or 64: MT / 16 A operands per unpacked B fragment), WIN the tables as a window.
+//
+// WIN (long K, or 64 rows per workgroup beyond K of about 4.6 K: the (scale | -(zero + bias) * scale) tables of ALL groups do not fit in LDS beside the
+// images).  The tables are a ring of two windows of WG = 4 * NK groups per column group (16 KB in all).  A window is what the workgroup's waves cross in
+// 2^gshift steps; every thread owns ONE entry of a window (NCG * WG * 16 lanes = 64 * NW), requests it from HBM one step before the window opens - behind
+// that step's activation chunks, in front of its weight rows, so waiting for it costs nothing the activation image does not already wait for - and puts it
+// in place in front of the barrier of the window's first step.  The other half of the ring is what slower waves may still be reading: its last reader
+// passed the previous step's barrier before any wave can reach this store.  Whether some scale of the tile needs the spliced form is settled by one pass
+// over the tile's scales at the opening.
+template <int BITS, int CPL, int NCG, int NW, int MT, bool WIN = false>
 __global__ void __launch_bounds__(64 * NW)
     gemv_rows_kernel(const uint32_t* qweight, uint32_t n, uint32_t xtiles, uint32_t kw, uint32_t units, const uint16_t* a, const uint16_t* scales, const uint32_t* qzeros,
                      uint16_t* out, uint32_t k, uint32_t groups, uint32_t zw, uint32_t bias, uint32_t m, uint32_t tab_groups, uint32_t gshift, uint32_t red_dwords) {
@@ -54,6 +63,8 @@ __global__ void __launch_bounds__(64 * NW)
   static_assert(NCG == 2 || NCG == 4, "column groups per workgroup");
   static_assert(MT == 32 || MT == 64, "rows per workgroup");
   static_assert(TASKS % (64 * NCG) == 0, "a unit's chunks split evenly over the sibling waves");
+  constexpr uint32_t WG = 4 * NK, RING = 2 * WG;  // WIN: groups per window, groups in the ring
+  static_assert(NCG * WG * NL == 64 * NW, "one table entry of a window per thread");
   constexpr uint32_t kOob = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];
   // LDS: [activation images: NK k-slices x 2 buffers x IMG][tables: NCG x tab_groups x NL lanes x 16 B][bad flags: NW dwords]; the reduction scratch (NW x MT x CN
@@ -157,28 +168,76 @@ __global__ void __launch_bounds__(64 * NW)
 
   // ---- the (scale | -(zero + bias) * scale) table of every column group, staged by all threads in a loop (a launch of this size is not bound by its opening)
   bool bad = false;
-  for (uint32_t e = (uint32_t)tid; e < (uint32_t)NCG * tab_groups * (uint32_t)NL; e += (uint32_t)(64 * NW)) {
-    const uint32_t cge = e / (tab_groups * (uint32_t)NL), ee = e % (tab_groups * (uint32_t)NL), g = ee / NL, snl = ee % NL;
-    const uint32_t scol = (xt * (uint32_t)NCG + cge) * CN + (uint32_t)CPL * snl;
-    const uint32_t h0 = g * n + scol;  // first scale (half index); n is even
-    const u32x2_t sv = __builtin_amdgcn_raw_buffer_load_b64(r_s, (h0 & ~1u) * 2u, 0, 0);
-    const uint32_t sh = (h0 & 1u) * 16u;
+  // one entry: CPL columns of one group.  sv / zv: the 8 bytes that hold the scales from halfword (h0 & ~1) on, the zero-points from dword (scol * BITS) / 32 on
+  auto tab_entry = [&](const u32x2_t sv, const u32x2_t zv, uint32_t scol) -> u32x4_t {
+    const uint32_t sh = (scol & 1u) * 16u;  // n is even: the parity of g * n + scol is scol's
     const uint32_t lo = __builtin_amdgcn_alignbit(sv.y, sv.x, sh), hi = sv.y >> sh;
-    uint32_t sb[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
-    const uint32_t bit = scol * BITS, zsh = bit & 31u;
-    const u32x2_t zv = __builtin_amdgcn_raw_buffer_load_b64(r_z, (g * zw + (bit >> 5)) * 4u, 0, 0);  // a read past the row end is harmless
-    const uint32_t zwin = __builtin_amdgcn_alignbit(zv.y, zv.x, zsh);
+    const uint32_t sb[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+    const uint32_t zwin = __builtin_amdgcn_alignbit(zv.y, zv.x, (scol * BITS) & 31u);
     u32x4_t ent = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const _Float16 s = as_h((uint16_t)sb[c]);
       const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + bias;
-      bool ok;
-      (void)sub_scale<BITS>(s, ok);
-      bad = bad || (!ok && g < groups && scol + (uint32_t)c < n);
       ent[c] = (uint32_t)as_u16(s) | ((uint32_t)as_u16(neg_zero_times_scale(z, s)) << 16);
     }
-    *reinterpret_cast<u32x4_t*>(s_tab + (cge * tab_groups * (uint32_t)NL + ee) * 4u) = ent;
+    return ent;
+  };
+  // WIN: this thread's entry of a window - column group t_cge, group t_g of the window, lane t_snl's columns
+  const uint32_t t_cge = (uint32_t)tid / (WG * NL), t_g = ((uint32_t)tid % (WG * NL)) / NL, t_snl = (uint32_t)tid % NL;
+  const uint32_t t_scol = (xt * (uint32_t)NCG + t_cge) * CN + (uint32_t)CPL * t_snl;
+  u32x2_t tw_s = {0u, 0u}, tw_z = {0u, 0u};
+  auto tab_issue = [&](uint32_t w) {
+    const uint32_t g = w * WG + t_g;
+    const bool in = g < groups;  // a window may reach past the last group (zeros: nothing reads them)
+    tw_s = __builtin_amdgcn_raw_buffer_load_b64(r_s, in ? ((g * n + t_scol) & ~1u) * 2u : kOob, 0, 0);
+    tw_z = __builtin_amdgcn_raw_buffer_load_b64(r_z, in ? (g * zw + ((t_scol * BITS) >> 5)) * 4u : kOob, 0, 0);
+  };
+  auto tab_store = [&](uint32_t w) {
+    const uint32_t g = w * WG + t_g;
+    *reinterpret_cast<u32x4_t*>(s_tab + ((t_cge * RING + (g & (RING - 1u))) * (uint32_t)NL + t_snl) * 4u) = tab_entry(tw_s, tw_z, t_scol);
+  };
+  if constexpr (!WIN) {
+    for (uint32_t e = (uint32_t)tid; e < (uint32_t)NCG * tab_groups * (uint32_t)NL; e += (uint32_t)(64 * NW)) {
+      const uint32_t cge = e / (tab_groups * (uint32_t)NL), ee = e % (tab_groups * (uint32_t)NL), g = ee / NL, snl = ee % NL;
+      const uint32_t scol = (xt * (uint32_t)NCG + cge) * CN + (uint32_t)CPL * snl;
+      const uint32_t h0 = g * n + scol;  // first scale (half index); n is even
+      const u32x2_t sv = __builtin_amdgcn_raw_buffer_load_b64(r_s, (h0 & ~1u) * 2u, 0, 0);
+      const uint32_t sh = (h0 & 1u) * 16u;
+      const uint32_t lo = __builtin_amdgcn_alignbit(sv.y, sv.x, sh), hi = sv.y >> sh;
+      uint32_t sb[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+      const uint32_t bit = scol * BITS, zsh = bit & 31u;
+      const u32x2_t zv = __builtin_amdgcn_raw_buffer_load_b64(r_z, (g * zw + (bit >> 5)) * 4u, 0, 0);  // a read past the row end is harmless
+      const uint32_t zwin = __builtin_amdgcn_alignbit(zv.y, zv.x, zsh);
+      u32x4_t ent = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const _Float16 s = as_h((uint16_t)sb[c]);
+        const uint32_t z = ((zwin >> (c * BITS)) & Unpack<BITS>::kMask) + bias;
+        bool ok;
+        (void)sub_scale<BITS>(s, ok);
+        bad = bad || (!ok && g < groups && scol + (uint32_t)c < n);
+        ent[c] = (uint32_t)as_u16(s) | ((uint32_t)as_u16(neg_zero_times_scale(z, s)) << 16);
+      }
+      *reinterpret_cast<u32x4_t*>(s_tab + (cge * tab_groups * (uint32_t)NL + ee) * 4u) = ent;
+    }
+  } else {
+    tab_issue(0u);
+    for (uint32_t e = (uint32_t)tid; e < (uint32_t)NCG * groups * (uint32_t)NL; e += (uint32_t)(64 * NW)) {  // the scales of the whole tile: do all take the subnormal form?
+      const uint32_t cge = e / (groups * (uint32_t)NL), ee = e % (groups * (uint32_t)NL), g = ee / NL, snl = ee % NL;
+      const uint32_t scol = (xt * (uint32_t)NCG + cge) * CN + (uint32_t)CPL * snl, h0 = g * n + scol;
+      const u32x2_t sv = __builtin_amdgcn_raw_buffer_load_b64(r_s, (h0 & ~1u) * 2u, 0, 0);
+      const uint32_t sh = (h0 & 1u) * 16u;
+      const uint32_t lo = __builtin_amdgcn_alignbit(sv.y, sv.x, sh), hi = sv.y >> sh;
+      const uint32_t sb[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        bool ok;
+        (void)sub_scale<BITS>(as_h((uint16_t)sb[c]), ok);
+        bad = bad || (!ok && scol + (uint32_t)c < n);
+      }
+    }
+    tab_store(0u);
   }
   {
     const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
@@ -201,7 +260,9 @@ __global__ void __launch_bounds__(64 * NW)
   const uint32_t sub_mask = opaque_sgpr(Unpack<BITS>::kSubMask2);
   const typename Unpack<BITS>::Consts uk = Unpack<BITS>::consts();
   const uint32_t a_lane = (uint32_t)(kl * UB) * (uint32_t)(4 * OST) + (uint32_t)nl * 4u;
-  const uint32_t* const my_tab = s_tab + (uint32_t)cg * tab_groups * (uint32_t)(NL * 4);
+  const uint32_t* const my_tab = s_tab + (uint32_t)cg * (WIN ? RING : tab_groups) * (uint32_t)(NL * 4);
+  const uint32_t ws_mask = (1u << gshift) - 1u;  // WIN: a window is 2^gshift steps
+  uint32_t stepi = 0;
 
   auto step = [&](const Row<CPL, true>(&X)[R], const uint32_t* a_unit, auto s_c, auto fast_c, const half2_t(&s2)[CPL], const half2_t(&nzs2)[CPL], const half2_t(&ss2)[CPL]) {
     constexpr int s = decltype(s_c)::value, j = s / 4, oct = s % 4;
@@ -240,12 +301,18 @@ __global__ void __launch_bounds__(64 * NW)
   auto process = [&](Row<CPL, true>(&X)[R], Row<CPL, true>(&Y)[R], int buf, auto fast_c) {
     const bool live = cur < units;  // wave-uniform
     if (live) act_store(cur, buf);  // this unit's activations: requested one step ago, the oldest loads in flight
-    act_issue(nxt);                 // the next unit's: in front of every row this step requests for it
+    if constexpr (WIN) {
+      if (stepi != 0u && (stepi & ws_mask) == 0u) tab_store(stepi >> gshift);  // a window opens with this step: its entries were requested one step ago
+    }
+    act_issue(nxt);  // the next unit's: in front of every row this step requests for it
+    if constexpr (WIN) {
+      if (((stepi + 1u) & ws_mask) == 0u) tab_issue((stepi + 1u) >> gshift);
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS stores only: the row loads stay in flight
     half2_t s2[CPL], nzs2[CPL], ss2[CPL];
     if (live) {
-      const uint32_t gi = (cur * (uint32_t)LK + (uint32_t)kl) >> gshift;
+      const uint32_t gi = ((cur * (uint32_t)LK + (uint32_t)kl) >> gshift) & (WIN ? RING - 1u : 0xFFFFFFFFu);
       const u32x4_t ent = *reinterpret_cast<const u32x4_t*>(my_tab + (gi * (uint32_t)NL + (uint32_t)nl) * 4u);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
@@ -268,6 +335,7 @@ __global__ void __launch_bounds__(64 * NW)
     cur = nxt;
     nxt = nn;
     nn += (uint32_t)NK;
+    ++stepi;
   };
   const uint32_t nsteps = (units + (uint32_t)NK - 1u) / (uint32_t)NK;  // the same for every wave: every wave passes every barrier
   if (fast) {
@@ -303,15 +371,16 @@ __global__ void __launch_bounds__(64 * NW)
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------
 
-template <int BITS, int CPL, int NCG, int NW, int MT>
+template <int BITS, int CPL, int NCG, int NW, int MT, bool WIN = false>
 int launch_rows_one(const GemvParams& g, hipStream_t stream, uint32_t units, uint32_t tab_groups, uint32_t gshift) {
   constexpr int CN = 16 * CPL, NK = NW / NCG, IMG = 4 * dyn::dyn_ub<BITS>() * 4 * (MT + 1) * 4;
   const uint32_t tiles = (g.n + CN - 1u) / CN, xtiles = (tiles + NCG - 1u) / NCG, row_blocks = (g.m + MT - 1u) / MT;
+  if (WIN) tab_groups = 2u * 4u * (uint32_t)NK;  // the ring of two windows
   const uint32_t front = (uint32_t)(NK * 2 * IMG) + (uint32_t)NCG * tab_groups * 64u, red = (uint32_t)(NW * MT * CN);  // dwords
   uint32_t red_dwords = front > red ? front : red;
   const size_t lds = (size_t)red_dwords * 4u + (size_t)NW * 4u;
   if (lds > dyn::kDynMaxLdsById) return kGemvDynNotEligible;
-  auto kern = gemv_rows_kernel<BITS, CPL, NCG, NW, MT>;
+  auto kern = gemv_rows_kernel<BITS, CPL, NCG, NW, MT, WIN>;
   GemvParams q = g;
   uint32_t xt = xtiles, un = units, tg = tab_groups, gs = gshift;
   void* args[] = {&q.qweight, &q.n, &xt, &q.kw, &un, &q.a, &q.scales, &q.qzeros, &q.out, &q.k, &q.groups, &q.zw, &q.bias, &q.m, &tg, &gs, &red_dwords};
@@ -355,17 +424,26 @@ int launch_rows_bits(const GemvParams& g, hipStream_t stream, int force_cpl = 0,
     if ((uint64_t)units * unit_bytes >= (1ull << 31) || (uint64_t)g.kw * g.n * 4u >= (1ull << 31) || (uint64_t)g.groups * g.n * 2u >= (1ull << 31) ||
         (uint64_t)g.m * g.k * 2u >= (1ull << 31))
       return kGemvDynNotEligible;
+    // every shape with the tables of all groups in LDS first; where they do not fit beside the images (K beyond about 14 K at 32 rows per workgroup, about 4.6 K at 64), the
+    // two-groups-of-columns shapes with the tables as a window (WIN)
     auto launch = [&](int cpl, int ncg, int mt) -> int {
+      int st = kGemvDynNotEligible;
       if (mt == 64) {  // four A operands per unpacked B fragment: 48-column groups only (64-column ones never won: profiles/r04/rows_lab_64_rows.txt)
         if constexpr (UB == 1) {
           if (cpl != 3) return kGemvDynNotEligible;
-          return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 64>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 64>(g, stream, units, tab_groups, gshift);
-        } else {
-          return kGemvDynNotEligible;  // 2-bit: a unit is 256 k - the images of 64 rows do not fit in LDS
+          st = ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 64>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 64>(g, stream, units, tab_groups, gshift);
+          if (st == kGemvDynNotEligible && ncg == 2) st = launch_rows_one<BITS, 3, 2, kRowsWaves, 64, true>(g, stream, units, tab_groups, gshift);
         }
+        return st;  // 2-bit: a unit is 256 k - the images of 64 rows do not fit in LDS
       }
-      if (cpl == 4) return ncg == 4 ? launch_rows_one<BITS, 4, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 4, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
-      return ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
+      if (cpl == 4) {
+        st = ncg == 4 ? launch_rows_one<BITS, 4, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 4, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
+        if (st == kGemvDynNotEligible && ncg == 2) st = launch_rows_one<BITS, 4, 2, kRowsWaves, 32, true>(g, stream, units, tab_groups, gshift);
+        return st;
+      }
+      st = ncg == 4 ? launch_rows_one<BITS, 3, 4, kRowsWaves, 32>(g, stream, units, tab_groups, gshift) : launch_rows_one<BITS, 3, 2, kRowsWaves, 32>(g, stream, units, tab_groups, gshift);
+      if (st == kGemvDynNotEligible && ncg == 2) st = launch_rows_one<BITS, 3, 2, kRowsWaves, 32, true>(g, stream, units, tab_groups, gshift);
+      return st;
     };
     if (force_cpl != 0 || force_ncg != 0 || force_mt != 0) {
       if ((force_cpl != 3 && force_cpl != 4) || (force_ncg != 2 && force_ncg != 4) || (force_mt != 32 && force_mt != 64)) return kGemvDynNotEligible;

@@ -91,14 +91,13 @@ constexpr Rule kRules[] = {
     // ---- more than 32 rows ---------------------------------------------------------------------------------------------------------
     {"2-bit, 33-64 rows, < 320 tiles of 32 columns: 16-row passes", bit_set(2, 2), 33, 64, 0, kAny, 0, kAny, 0, kAny, 0, 319, 0, 0, Act::MfmaDefault,
      "profiles/r04/sweep_rows_w2.txt (2-bit units are 256 k: two row blocks of a narrow layer do not fill the chip - 4096x4096 at 64 rows 11.0 us against 15.0, 8192x8192 35.2 / 42.4; 4096x11008 wins: 16.4 against 25.6)"},
-    {"2-bit, 65-128 rows, < 192 tiles of 32 columns, K > 4096: 16-row passes", bit_set(2, 2), 65, 128, 129, kAny, 0, kAny, 0, kAny, 0, 191, 0, 0, Act::MfmaDefault,
-     "profiles/r04/check_rules_9.txt (6144x4096 w2 at 96 rows: 25.5 us against 32.9 - the images of two column groups and the table of a K beyond 4096 do not fit in LDS, four groups are too wide for 128 tiles; 4096x4096 at 128 rows stays: 15.2 against 20.1)"},
     {"33-512 rows, >= 192 tiles of 32 columns: one launch over blocks of 32 / 64 rows", kAllBits, 33, 512, 0, kAny, 0, kAny, 0, kAny, 192, kAny, 0, 0, Act::DynChunks32,
      "profiles/r04/sweep_rows_shared_tile_v1.txt, sweep_rows_group64_32.txt (group 64 / 32: 4096x11008 w4 at 128 rows 40.0 us against 45.7 in 16-row passes), sweep_rows_192_256.txt (256 rows: 54.7 us against 88.5; dequantise + dense GEMM 72.9: linear_crossover_2.txt), sweep_rows_shared_tile_v2.txt (64 rows per workgroup: 38.1), sweep_rows_in_grid_y.txt"},
     {"129-512 rows, fewer tiles", kAllBits, 129, 512, 0, kAny, 0, kAny, 0, kAny, 0, 191, 0, 0, Act::DynChunks32,
      "profiles/r04/sweep_rows_192_256.txt (4096x4096 w4 at 192 / 256 rows: 17.9 / 18.7 us against 30.0 / 39.8 in 16-row passes)"},
     {"33-128 rows, 96-191 tiles of 32 columns, groups of 128 and more", kAllBits, 33, 128, 0, kAny, 0, kAny, 0, kAny, 96, 191, kGroupA, 0, Act::DynChunks32,
-     "profiles/r04/sweep_rows_shared_tile_v1.txt (4096x4096 w4 at 64 / 128 rows: 9.4 / 17.4 us against 12.1 / 21.4; 11008x4096: 21.9 / 40.9 against 27.8 / 51.3), sweep_rows_group64_32.txt (group 32 loses there: 21.6 against 18.4), check_rules_3.txt (6144x2048 at 64 rows loses: 12.2 against 10.9)"},
+     "profiles/r04/sweep_rows_shared_tile_v1.txt (4096x4096 w4 at 64 / 128 rows: 9.4 / 17.4 us against 12.1 / 21.4; 11008x4096: 21.9 / 40.9 against 27.8 / 51.3), sweep_rows_group64_32.txt (group 32 loses there: 21.6 against 18.4), check_rules_3.txt (6144x2048 at 64 rows loses: 12.2 against 10.9), "
+     "sweep_rows_w2_few_tiles_long_k.txt (2-bit at K > 4096 had a row of its own here - 16-row passes, the tables did not fit in LDS - until the tables became a window: 6144x4096 w2 at 96 / 128 rows 24.8 / 32.2 us -> 20.5 / 20.8, 5120x5120 30.8 / 38.3 -> 18.1 / 18.6, 8192x3584 25.2 / 32.3 -> 25.8 / 25.8)"},
     // ---- the staged-operand kernel, whole K ----------------------------------------------------------------------------------------
     {"17-32 rows, >= 192 tiles: 32-row build", kAllBits, 17, 32, 0, kAny, 0, kAny, 192, kAny, 0, kAny, kGroupA, 0, Act::DynWhole,
      "profiles/r03/sweep_rows_17_32.txt (4096x11008 w4 15.2 -> 11.5 us; few tiles lose: 4096x4096 7.4 -> 8.6)"},
