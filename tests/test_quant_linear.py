@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import oracle
-from xbitops_amd import packing
+from xbitops_amd import _lib, packing
 
 
 @pytest.mark.parametrize("bits,bias", [(2, 0), (3, 1), (4, 1), (8, 0)])
@@ -61,6 +61,22 @@ def test_quant_linear_forward(bits, bias, cuda_device):
     assert y.shape == (600, 128)
     assert (np.abs(y.float().cpu().numpy() - y_ref) <= 2e-3 * np.abs(y_ref) + 1e-3).all()
     assert layer(torch.zeros(2, 3, 512, device=cuda_device).half()).shape == (2, 3, 128)
+
+
+@pytest.mark.gpu
+def test_quant_linear_long_k_stays_on_the_fused_path(cuda_device):
+    """A down-projection with a long K (192 groups: their tables do not fit in LDS beside the activation images) at prefill-sized row counts: the module keeps the
+    fused path up to GEMV_MAX_ROWS (the rows kernel's windowed-table builds; profiles/r04/linear_crossover_long_k.txt) and equals the oracle on its own packed buffers."""
+    from xbitops_amd.linear import QuantLinear
+
+    torch.manual_seed(11)
+    k, n = 24576, 256
+    layer = QuantLinear.from_float(torch.randn(k, n) * 0.05, bits=4, groupsize=128, add_zero_bias=1).to(cuda_device)
+    for rows in (100, 300):
+        x = (torch.randn(rows, k, device=cuda_device) * 0.5).half()
+        recs = _lib.dry_run(_lib.load(), lambda: layer(x))
+        assert len(recs) == 1 and "gemv_rows_kernel<4," in recs[0]["kernel"] and ", true>" in recs[0]["kernel"], recs
+        _assert_close_to_oracle(layer(x), _oracle_forward(layer, x), "long K rows=%d" % rows)
 
 
 @pytest.mark.gpu

@@ -17,7 +17,8 @@ from . import ops, packing
 # (profiles/r04/linear_crossover.txt, us per call): 4096x11008 w4 11.8 against 45.5 at 32 rows, 18.0 / 49.6 at 64,
 # 24.3 / 60.5 at 128, 40.1 / 75.7 at 256, 69.3 / 89.8 at 384, 79.1 / 94.2 at 512 (8192x8192: 36.8 / 107.5 at 128, 129.9 / 131.9 at
 # 512: level).  The dense path starts near 40 us whatever the row count (19 us of dequant + a small-M GEMM) and gains 0.1 us per
-# row; the fused one gains 0.15 from 64 rows on - they meet near 512.
+# row; the fused one gains 0.15 from 64 rows on - they meet near 512.  Long K (the rows kernel keeps the tables as a window there): 28672x8192 w4 96 against 310 us at 64 rows,
+# 126 / 309 at 128, 237 / 392 at 256, 402 / 486 at 512; 14336x4096 111 / 164 at 512 (profiles/r04/linear_crossover_long_k.txt).
 GEMV_MAX_ROWS = 512
 GEMV_MAX_ROWS_2BIT = 512  # (profiles/r04/linear_crossover_w2.txt: 4096x11008 w2 at 256 rows 54.7 against 70.8, at 512 rows 92.0 / 94.7)
 # ... for layers the multi-row builds take: a group size that is a power-of-two multiple of 32 (64 at 2 bits), ANY in_features (round 4:
