@@ -65,14 +65,14 @@ def test_quant_linear_forward(bits, bias, cuda_device):
 
 @pytest.mark.gpu
 def test_quant_linear_long_k_stays_on_the_fused_path(cuda_device):
-    """A down-projection with a long K (192 groups: their tables do not fit in LDS beside the activation images) at prefill-sized row counts: the module keeps the
+    """A down-projection with many groups (12288 / 64 = 192: their tables do not fit in LDS beside the activation images) at prefill-sized row counts: the module keeps the
     fused path up to GEMV_MAX_ROWS (the rows kernel's windowed-table builds; profiles/r04/linear_crossover_long_k.txt) and equals the oracle on its own packed buffers."""
     from xbitops_amd.linear import QuantLinear
 
     torch.manual_seed(11)
-    k, n = 24576, 256
-    layer = QuantLinear.from_float(torch.randn(k, n) * 0.05, bits=4, groupsize=128, add_zero_bias=1).to(cuda_device)
-    for rows in (100, 300):
+    k, n = 12288, 3072  # (a layer of fewer than 96 tiles of 32 columns takes 16-row passes up to 128 rows: xbit_gemv_rules.h)
+    layer = QuantLinear.from_float(torch.randn(k, n) * 0.05, bits=4, groupsize=64, add_zero_bias=1).to(cuda_device)
+    for rows in (200, 400):
         x = (torch.randn(rows, k, device=cuda_device) * 0.5).half()
         recs = _lib.dry_run(_lib.load(), lambda: layer(x))
         assert len(recs) == 1 and "gemv_rows_kernel<4," in recs[0]["kernel"] and ", true>" in recs[0]["kernel"], recs
