@@ -86,10 +86,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--slack", type=float, default=1.08)
     ap.add_argument("--points", default="all", choices=("all", "quick", "long_k"))
+    ap.add_argument("--only", default="", help="bits,rows,K,N,group[;...]: these points instead of a list")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     prod, tun = _lib.load(), _lib.load_tuning()
     points = POINTS if args.points == "all" else LONG_K if args.points == "long_k" else QUICK
+    if args.only:
+        points = [tuple(int(x) for x in pt.split(",")) for pt in args.only.split(";")]
     print("# device %s; period of a dependent chain of launches, cold, us; the automatic launch (production library) against every forced launch; slack %.2f" % (
         torch.cuda.get_device_name(0), args.slack), flush=True)
     failed = 0
@@ -99,22 +102,32 @@ def main():
         def period(lib, variant, split):
             return gemv_sweep.gemv_case(lib, dev, k, n, bits, g, m, True, iters, variant, split, both=True)[4]
 
-        auto = period(prod, -1, 0)
-        best, best_label, cells = auto, "automatic", []
-        for label, v, s in candidates(bits, m, k, n, g):
-            try:
-                t = period(tun, v, s)
-            except AssertionError:
-                continue
-            cells.append("%s %.2f" % (label, t))
-            if t < best:
-                best, best_label = t, label
-        auto2 = period(prod, -1, 0)  # the automatic launch once more, after the others: the box drifts by a per cent or two over a point
-        auto = min(auto, auto2)
-        ok = auto <= args.slack * best
+        def measure():
+            auto = period(prod, -1, 0)
+            best, best_label, cells = auto, "automatic", []
+            for label, v, s in candidates(bits, m, k, n, g):
+                try:
+                    t = period(tun, v, s)
+                except AssertionError:
+                    continue
+                cells.append("%s %.2f" % (label, t))
+                if t < best:
+                    best, best_label = t, label
+            auto2 = period(prod, -1, 0)  # the automatic launch once more, after the others: the box drifts by a per cent or two over a point
+            auto = min(auto, auto2)
+            return auto, best, best_label, cells
+
+        # "best" is the minimum of a dozen single measurements, each with a spread of a few per cent (the same launch under two labels has read 20.3 and 22.2 us
+        # in one run: profiles/r04/check_rules_10.txt), so a ratio just above the slack may be that spread: a point fails only if a second pass over it fails too
+        for attempt in (1, 2):
+            auto, best, best_label, cells = measure()
+            ok = auto <= args.slack * best
+            tag = "ok  " if ok else ("FAIL" if attempt == 2 else "again")
+            print("%s w%d m%-3d %5dx%-5d g%-3d  automatic %7.2f  best %7.2f (%s)  ratio %.3f" % (tag, bits, m, k, n, g, auto, best, best_label, auto / best), flush=True)
+            print("       " + "; ".join(cells), flush=True)
+            if ok:
+                break
         failed += 0 if ok else 1
-        print("%s w%d m%-3d %5dx%-5d g%-3d  automatic %7.2f  best %7.2f (%s)  ratio %.3f" % ("ok  " if ok else "FAIL", bits, m, k, n, g, auto, best, best_label, auto / best), flush=True)
-        print("       " + "; ".join(cells), flush=True)
     print("# %d of %d points within %.2f x the best forced launch" % (len(points) - failed, len(points), args.slack), flush=True)
     return 1 if failed else 0
 
