@@ -215,6 +215,36 @@ def test_gemv_w4_llama70b_ffn_shard_and_full(cuda_device):
     assert_gemv_close(y_full[:, 5 * 3584:6 * 3584].cpu().numpy(), y_ref, "cfg4 shard 5", k=p.k)
 
 
+def test_gemv_w4_llama70b_down_projection_128_rows_full_size(cuda_device):
+    """The 70B down-projection (28672x8192, 224 groups: the rows kernel with its tables as a window) at 128 rows and full size: a column shard against the
+    oracle, and two size-independent properties - the result restricted to a column shard equals the GEMV of that shard alone, and a row of the batch equals
+    the one-row GEMV of that row (other kernels, other summation orders: to the last fp16 bit)."""
+    import XbitOps
+    from xbitops_amd import sharded
+
+    k, n, m = 28672, 8192, 128
+    p = synth.make_problem(k, n, 4, 128, m=m, seed=70)
+    a, qw, sc, qz = to_dev(p, cuda_device)
+    y_full = XbitOps.gemv(a, qw, sc, qz, 128, 4, k, 1)
+    assert y_full.shape == (m, n)
+
+    def same_to_the_last_bit(y1, y2, what):
+        d = (y1.view(torch.int16).int() - y2.view(torch.int16).int()).abs()
+        near_zero = (y1.float() - y2.float()).abs() <= contract.cancel_slack(k)
+        assert bool(((d <= 1) | near_zero).all()) and float((d == 0).float().mean()) > 0.97, what
+
+    for r in (0, 13):  # 16 shards of 512 columns
+        qw_r, sc_r, qz_r = sharded.shard_columns(qw, sc, qz, 4, 16, r)
+        y_r = XbitOps.gemv(a, qw_r, sc_r, qz_r, 128, 4, k, 1)
+        same_to_the_last_bit(y_r, y_full[:, r * 512:(r + 1) * 512].contiguous(), ("shard", r))
+    for row in (0, 77, 127):
+        y_1 = XbitOps.gemv(a[row:row + 1].contiguous(), qw, sc, qz, 128, 4, k, 1)
+        same_to_the_last_bit(y_1, y_full[row:row + 1].contiguous(), ("row", row))
+    qw_r, sc_r, qz_r = sharded.shard_columns(p.qweight, p.scales, p.qzeros, 4, 16, 13)
+    y_ref = oracle.gemv(p.act, qw_r, sc_r, qz_r, 128, 4, k, 1, oracle.RNE)
+    assert_gemv_close(y_full[:, 13 * 512:14 * 512].cpu().numpy(), y_ref, "70B down-projection, 128 rows, shard 13", k=k)
+
+
 def test_gemv_w4_llama7b_ffn_full_size(cuda_device):
     """BASELINE.json config 2 at full size."""
     p = synth.make_problem(4096, 11008, 4, 128, m=1, seed=2)
