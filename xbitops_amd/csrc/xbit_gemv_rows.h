@@ -14,7 +14,7 @@
 // Measured, chain period, w4 (profiles/r04/sweep_rows_shared_tile_v1.txt, _v2.txt, sweep_rows_320_512.txt; tools/microbench/rows_lab.hip is the harness
 // the kernel was developed in): 4096x11008 at 64 / 128 / 256 / 512 rows 21.7 / 40.4 / 75.3 / 172.6 us (grid.y launch; 16-row passes at 512) ->
 // 17.7 / 23.1 / 38.1 / 69.1; 8192x8192 at 128 rows 60.3 -> 34.1.  Long K (tables as a window, WIN below; profiles/r04/sweep_rows_long_k.txt, sweep_rows_long_k_w2.txt): 28672x8192 at 64 / 128 /
-// 256 / 512 rows 101 / 192 / 380 / 826 us (32-row build in grid.y; 16-row passes at 512) -> 84 / 105 / 203 / 361; 14336x4096 at 256 / 512 rows 96 / 244 -> 55 / 95.
+// 256 / 512 rows 101 / 192 / 380 / 826 us (32-row build in grid.y; 16-row passes at 512) -> 84 / 105 / 203 / 361; 2-bit at group 64: 11008x4096 at 256 rows 73 -> 45.5.
 // What a workgroup's time follows (profiles/r04/rows_lab_ablations.txt, rows_pmc_summary.txt, rows_lab_64_rows.txt): no single stage - but across the six
 // shapes it is 28-38 ns per wave-level load instruction the workgroup issues (K = 4096: 2 x 48 columns x 32 rows 512 loads, 16.7 us; 4 x 48 x 32: 768,
 // 24.6; 2 x 48 x 64: 768, 21.4; 4 x 48 x 64: 1024, 33.4), whatever else is removed or added: a CU's vector-memory pipeline is the serial resource.
